@@ -1,0 +1,489 @@
+// api.hip -- the C-ABI of libgpak_hip.so (see include/gpak.h for the contract and the
+// reference members each entry point replaces).  Orchestration only; kernels live in
+// gram.hip / gemm.hip / potrf.hip / solve.hip / predict.hip.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+#include "gpak_internal.h"
+
+int gpak_calibrate_impl(gpak_ctx *ctx, double *scratch, size_t scratch_bytes, double *tflops, double *gbs);
+int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var);
+int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k);
+int gpak_grad_impl(gpak_ctx *ctx, double *g);
+
+static std::string g_global_err;
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static void free_points(DevPoints &p) {
+  if (p.u0) hipFree(p.u0);
+  p = DevPoints();
+}
+int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap) {
+  if (p.cap >= cap) return GPAK_OK;
+  free_points(p);
+  double *base = nullptr;
+  if (hipMalloc(&base, sizeof(double) * 4 * (size_t)cap) != hipSuccess) {
+    ctx->err = "hipMalloc(points) failed";
+    return GPAK_ENOMEM;
+  }
+  p.u0 = base; p.u1 = base + cap; p.u2 = base + 2 * (size_t)cap; p.s = base + 3 * (size_t)cap;
+  p.cap = cap;
+  return GPAK_OK;
+}
+
+// sigInv = Rot * lambda * Rot^T, Kernel.cpp:1399-1425 (host, 3x3)
+static void build_siginv(const double *e, double *A) {
+  const double alpha = e[0], beta = e[2], teta = e[4];
+  const double lam[3] = {e[1], e[3], e[5]};
+  double R[9];
+  const double ca = std::cos(alpha), sa = std::sin(alpha), cb = std::cos(beta), sb = std::sin(beta);
+  const double ct = std::cos(teta), st = std::sin(teta);
+  R[0 + 0 * 3] = ca * ct + sa * sb * st;
+  R[0 + 1 * 3] = -sa * ct + ca * sb * st;
+  R[0 + 2 * 3] = -cb * st;
+  R[1 + 0 * 3] = sa * cb;
+  R[1 + 1 * 3] = ca * cb;
+  R[1 + 2 * 3] = sb;
+  R[2 + 0 * 3] = ca * st - sa * sb * ct;
+  R[2 + 1 * 3] = -sa * st - ca * sb * ct;
+  R[2 + 2 * 3] = cb * ct;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += R[r + k * 3] * lam[k] * R[c + k * 3];
+      A[r + c * 3] = s;
+    }
+}
+
+// pooled mean of X1 u X2 exactly as Kernel.cpp:1391-1392 computes it
+void gpak_pooled_mean(const double *s1, long n, const double *s2, long m, double *mu) {
+  for (int k = 0; k < 3; k++) {
+    double mX1 = (double)n / (double)(n + m) * s1[k] / (double)n;
+    mu[k] = (double)m / (double)(n + m) * s2[k] / (double)m + mX1;
+  }
+}
+
+static void release_train(gpak_ctx *ctx) {
+  if (ctx->dX) hipFree(ctx->dX);
+  if (ctx->dy) hipFree(ctx->dy);
+  if (ctx->dM) hipFree(ctx->dM);
+  if (ctx->dInv) hipFree(ctx->dInv);
+  if (ctx->dAlpha) hipFree(ctx->dAlpha);
+  if (ctx->dWork) hipFree(ctx->dWork);
+  ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dAlpha = ctx->dWork = nullptr;
+  free_points(ctx->U);
+  ctx->N = ctx->Np = 0;
+  ctx->mstate = gpak_ctx::M_NONE;
+  ctx->alpha_ok = ctx->nlz_ok = false;
+}
+
+extern "C" {
+
+const char *gpak_global_error(void) { return g_global_err.c_str(); }
+
+int gpak_create(gpak_ctx **out, int device, int precision) {
+  if (!out) return GPAK_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_global_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count=0") +
+                   " (libgpak_hip has no CPU fallback)";
+    return GPAK_EHIP;
+  }
+  if (device < 0 || device >= count) { g_global_err = "device ordinal out of range"; return GPAK_EINVAL; }
+  if (precision != GPAK_F64) { g_global_err = "only GPAK_F64 is built in this round"; return GPAK_ENOTIMPL; }
+  if ((e = hipSetDevice(device)) != hipSuccess) { g_global_err = hipGetErrorString(e); return GPAK_EHIP; }
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_global_err = hipGetErrorString(e); return GPAK_EHIP; }
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    g_global_err = std::string("device is ") + prop.gcnArchName + ", libgpak_hip is built for gfx950 only";
+    return GPAK_EHIP;
+  }
+  gpak_ctx *ctx = new gpak_ctx();
+  ctx->device = device;
+  ctx->precision = precision;
+  memset(&ctx->times, 0, sizeof(ctx->times));
+  if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) { g_global_err = hipGetErrorString(e); delete ctx; return GPAK_EHIP; }
+  for (int i = 0; i < 8; i++) hipEventCreate(&ctx->ev[i]);
+  hipMalloc(&ctx->dRed, sizeof(double) * 64);
+  hipMalloc(&ctx->dInfo, sizeof(int) * 4);
+  const char *nb = getenv("GPAK_NB_OUTER");
+  if (nb) ctx->nb_outer = atoi(nb);
+  *out = ctx;
+  return GPAK_OK;
+}
+
+void gpak_destroy(gpak_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  release_train(ctx);
+  gpak_predict_release(ctx);
+  if (ctx->dRed) hipFree(ctx->dRed);
+  if (ctx->dInfo) hipFree(ctx->dInfo);
+  for (int i = 0; i < 8; i++) hipEventDestroy(ctx->ev[i]);
+  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *gpak_last_error(const gpak_ctx *ctx) { return ctx ? ctx->err.c_str() : g_global_err.c_str(); }
+
+int gpak_set_option(gpak_ctx *ctx, int option, long value) {
+  if (!ctx) return GPAK_EINVAL;
+  switch (option) {
+    case GPAK_OPT_MEMOISE: ctx->memoise = value != 0; return GPAK_OK;
+    case GPAK_OPT_NB_OUTER:
+      if (value < 128 || value % 128) { ctx->err = "nb_outer must be a positive multiple of 128"; return GPAK_EINVAL; }
+      ctx->nb_outer = (int)value;
+      return GPAK_OK;
+    case GPAK_OPT_PROFILE: ctx->profile = value != 0; return GPAK_OK;
+  }
+  ctx->err = "unknown option";
+  return GPAK_EINVAL;
+}
+
+int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d) {
+  if (!ctx || !X || !y || N <= 0) return GPAK_EINVAL;
+  if (d != 3) { ctx->err = "HIP path handles 3-D inputs (d=4 rock-type column: SURVEY.md Q7, not built)"; return GPAK_ENOTIMPL; }
+  GPAK_HIP(hipSetDevice(ctx->device));
+  release_train(ctx);
+  const int Np = round_up(N, GPAK_TILE);
+  long pad = Np >= 1024 ? 32 : 0;
+  if (const char *p = getenv("GPAK_LD_PAD")) pad = atol(p) / 2 * 2;
+  const long ld = Np + pad;
+  ctx->N = N; ctx->Np = Np; ctx->ld = (int)ld; ctx->d = d;
+  ctx->hX.assign(X, X + (size_t)N * d);
+  for (int k = 0; k < 3; k++) {
+    double s = 0.0;
+    for (int i = 0; i < N; i++) s += X[i + (size_t)k * N];
+    ctx->xsum[k] = s;
+  }
+  const int T = Np / GPAK_TILE;
+  if (hipMalloc(&ctx->dX, sizeof(double) * 3 * (size_t)Np) != hipSuccess ||
+      hipMalloc(&ctx->dy, sizeof(double) * (size_t)Np) != hipSuccess ||
+      hipMalloc(&ctx->dM, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
+      hipMalloc(&ctx->dInv, sizeof(double) * (size_t)T * 2 * GPAK_TILE * GPAK_TILE) != hipSuccess ||
+      hipMalloc(&ctx->dAlpha, sizeof(double) * (size_t)Np) != hipSuccess ||
+      hipMalloc(&ctx->dWork, sizeof(double) * 70 * (size_t)Np) != hipSuccess) {
+    ctx->err = "device allocation failed for the training set";
+    release_train(ctx);
+    return GPAK_ENOMEM;
+  }
+  int rc = gpak_alloc_points(ctx, ctx->U, Np);
+  if (rc) return rc;
+  GPAK_HIP(hipMemsetAsync(ctx->dX, 0, sizeof(double) * 3 * (size_t)Np, ctx->stream));
+  GPAK_HIP(hipMemsetAsync(ctx->dy, 0, sizeof(double) * (size_t)Np, ctx->stream));
+  GPAK_HIP(hipMemsetAsync(ctx->dAlpha, 0, sizeof(double) * (size_t)Np, ctx->stream));
+  for (int k = 0; k < 3; k++)
+    GPAK_HIP(hipMemcpyAsync(ctx->dX + (size_t)k * Np, X + (size_t)k * N, sizeof(double) * N,
+                            hipMemcpyHostToDevice, ctx->stream));
+  GPAK_HIP(hipMemcpyAsync(ctx->dy, y, sizeof(double) * N, hipMemcpyHostToDevice, ctx->stream));
+  GPAK_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->times.n = N; ctx->times.n_padded = Np;
+  ctx->U.n = 0;  // transformed points are rebuilt on the next use
+  return GPAK_OK;
+}
+
+int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2, int dist_mode) {
+  if (!ctx || !expans) return GPAK_EINVAL;
+  if (dist_mode != GPAK_DIST_EXPANSION && dist_mode != GPAK_DIST_DIRECT) { ctx->err = "bad dist_mode"; return GPAK_EINVAL; }
+  bool same = ctx->have_params && memcmp(expans, ctx->expans, sizeof(double) * 8) == 0 && bias == ctx->bias &&
+              sn2 == ctx->sn2 && dist_mode == ctx->dist_mode;
+  memcpy(ctx->expans, expans, sizeof(double) * 8);
+  ctx->bias = bias; ctx->sn2 = sn2; ctx->dist_mode = dist_mode;
+  ctx->have_params = true;
+  build_siginv(expans, ctx->kp.A);
+  ctx->kp.var2 = expans[6] * expans[6];
+  ctx->kp.bias = bias;
+  ctx->kp.mode = dist_mode;
+  if (!(same && ctx->memoise)) {
+    // GP_Utils.cpp:132-133: setKUpdateStat(false) -> K, alpha and the likelihood are stale
+    ctx->mstate = gpak_ctx::M_NONE;
+    ctx->alpha_ok = ctx->nlz_ok = false;
+    ctx->U.n = 0;
+  }
+  return GPAK_OK;
+}
+
+}  // extern "C"
+
+// transformed training points for the train x train Gram (pooled mean of X u X)
+int gpak_ensure_U(gpak_ctx *ctx) {
+  if (!ctx->N) { ctx->err = "no training set (gpak_set_train)"; return GPAK_ESTATE; }
+  if (!ctx->have_params) { ctx->err = "no parameters (gpak_set_params)"; return GPAK_ESTATE; }
+  if (ctx->U.n == ctx->N) return GPAK_OK;
+  gpak_pooled_mean(ctx->xsum, ctx->N, ctx->xsum, ctx->N, ctx->kp.mu);
+  gpak_launch_transform(ctx->stream, ctx->dX, ctx->Np, ctx->N, ctx->kp, ctx->U);
+  return GPAK_OK;
+}
+
+static int ensure_factor(gpak_ctx *ctx) {
+  if (ctx->mstate == gpak_ctx::M_L) return GPAK_OK;
+  int rc = gpak_ensure_U(ctx);
+  if (rc) return rc;
+  GPAK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  GPAK_HIP(hipEventRecord(ctx->ev[0], st));
+  // B = I + (sW sW') % K  with W = 1/sn2  (GP_Utils.cpp:898-902); lower tiles only
+  gpak_launch_fill(st, ctx->U, ctx->U, ctx->Np, ctx->Np, ctx->kp, 1.0 / ctx->sn2, 1.0, 1.0, 1, ctx->dM,
+                   ctx->ld, nullptr);
+  ctx->mstate = gpak_ctx::M_B;
+  GPAK_HIP(hipEventRecord(ctx->ev[1], st));
+  rc = gpak_potrf_blocked(ctx);
+  GPAK_HIP(hipEventRecord(ctx->ev[2], st));
+  GPAK_HIP(hipEventSynchronize(ctx->ev[2]));
+  float ms = 0;
+  GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+  ctx->times.gram_ms = ms;
+  GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+  ctx->times.factor_ms = ms;
+  ctx->times.gram_bytes = 8.0 * ((double)ctx->Np * (ctx->Np + GPAK_TILE) / 2.0);
+  if (rc == GPAK_ENOTPD) {
+    ctx->mstate = gpak_ctx::M_NONE;
+    ctx->err = "B = I + K/sn2 is not positive definite";
+    return rc;
+  }
+  if (rc) return rc;
+  ctx->mstate = gpak_ctx::M_L;
+  return GPAK_OK;
+}
+
+static int ensure_alpha(gpak_ctx *ctx) {
+  int rc = ensure_factor(ctx);
+  if (rc) return rc;
+  if (ctx->alpha_ok) return GPAK_OK;
+  hipStream_t st = ctx->stream;
+  double *w0 = ctx->dWork, *w1 = ctx->dWork + ctx->Np;
+  GPAK_HIP(hipEventRecord(ctx->ev[3], st));
+  // alpha = (K + sn2 I)^-1 y = B^-1 (y / sn2)
+  gpak_launch_scale(st, ctx->Np, ctx->dy, 1.0 / ctx->sn2, w0);
+  gpak_launch_trsv_fwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
+  gpak_launch_trsv_bwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha);
+  GPAK_HIP(hipEventRecord(ctx->ev[4], st));
+  GPAK_HIP(hipEventSynchronize(ctx->ev[4]));
+  float ms = 0;
+  GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+  ctx->times.solve_ms = ms;
+  ctx->alpha_ok = true;
+  return GPAK_OK;
+}
+
+static int ensure_nlz(gpak_ctx *ctx) {
+  int rc = ensure_alpha(ctx);
+  if (rc) return rc;
+  if (ctx->nlz_ok) return GPAK_OK;
+  hipStream_t st = ctx->stream;
+  double *f = ctx->dWork + 2 * (size_t)ctx->Np;
+  double *scratch = ctx->dWork + 4 * (size_t)ctx->Np;  // 64 * Np doubles available
+  GPAK_HIP(hipEventRecord(ctx->ev[5], st));
+  int splits = gpak_kmatvec_splits(ctx->N, ctx->N);
+  gpak_launch_kmatvec(st, ctx->U, ctx->dAlpha, ctx->U, ctx->kp, scratch, splits, f);  // f = K*Alpha
+  gpak_launch_logdet(st, ctx->N, ctx->dM, ctx->ld, ctx->dRed);
+  gpak_launch_nlz_terms(st, ctx->N, ctx->dy, f, ctx->dAlpha, ctx->sn2, ctx->dRed);
+  double red[3];
+  GPAK_HIP(hipMemcpyAsync(red, ctx->dRed, sizeof(red), hipMemcpyDeviceToHost, st));
+  GPAK_HIP(hipEventRecord(ctx->ev[6], st));
+  GPAK_HIP(hipEventSynchronize(ctx->ev[6]));
+  float ms = 0;
+  GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]));
+  ctx->times.nlz_ms = ms;
+  ctx->logdet = red[0]; ctx->quad = red[1]; ctx->sumlp = red[2];
+  ctx->nlz = ctx->quad - ctx->sumlp + ctx->logdet;  // GP_Utils.cpp:1159
+  ctx->nlz_ok = true;
+  return GPAK_OK;
+}
+
+// copy an n x m block (ld) of a device matrix to a dense host column-major array
+static int copy_out(gpak_ctx *ctx, const double *dsrc, long ld, int n, int m, double *host) {
+  GPAK_HIP(hipMemcpy2DAsync(host, sizeof(double) * n, dsrc, sizeof(double) * ld, sizeof(double) * n, m,
+                            hipMemcpyDeviceToHost, ctx->stream));
+  GPAK_HIP(hipStreamSynchronize(ctx->stream));
+  return GPAK_OK;
+}
+
+extern "C" {
+
+int gpak_gram(gpak_ctx *ctx, double *K_host, double *D2_host) {
+  if (!ctx) return GPAK_EINVAL;
+  GPAK_HIP(hipSetDevice(ctx->device));
+  int rc = gpak_ensure_U(ctx);
+  if (rc) return rc;
+  double *dD2 = nullptr;
+  if (D2_host && hipMalloc(&dD2, sizeof(double) * (size_t)ctx->ld * ctx->Np) != hipSuccess) {
+    ctx->err = "device allocation failed for D2";
+    return GPAK_ENOMEM;
+  }
+  // the matrix buffer is reused: whatever factor it held is gone
+  ctx->mstate = gpak_ctx::M_NONE;
+  ctx->alpha_ok = ctx->nlz_ok = false;
+  gpak_launch_fill(ctx->stream, ctx->U, ctx->U, ctx->Np, ctx->Np, ctx->kp, 1.0, 0.0, 0.0, 0, ctx->dM, ctx->ld,
+                   dD2);
+  rc = GPAK_OK;
+  if (K_host) rc = copy_out(ctx, ctx->dM, ctx->ld, ctx->N, ctx->N, K_host);
+  if (!rc && D2_host) rc = copy_out(ctx, dD2, ctx->ld, ctx->N, ctx->N, D2_host);
+  GPAK_HIP(hipStreamSynchronize(ctx->stream));
+  if (dD2) hipFree(dD2);
+  return rc;
+}
+
+int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int m, int d, double *K_host,
+                   double *D2_host) {
+  if (!ctx || !X1 || !X2 || n <= 0 || m <= 0) return GPAK_EINVAL;
+  if (d != 3) { ctx->err = "HIP path handles 3-D inputs"; return GPAK_ENOTIMPL; }
+  if (!ctx->have_params) { ctx->err = "no parameters (gpak_set_params)"; return GPAK_ESTATE; }
+  GPAK_HIP(hipSetDevice(ctx->device));
+  const int np = round_up(n, GPAK_TILE), mp = round_up(m, GPAK_TILE);
+  double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++) {
+    for (int i = 0; i < n; i++) s1[k] += X1[i + (size_t)k * n];
+    for (int i = 0; i < m; i++) s2[k] += X2[i + (size_t)k * m];
+  }
+  KernParams kp = ctx->kp;
+  gpak_pooled_mean(s1, n, s2, m, kp.mu);
+  DevPoints P, Q;
+  double *dx = nullptr, *dK = nullptr, *dD2 = nullptr;
+  int rc = gpak_alloc_points(ctx, P, np);
+  if (!rc) rc = gpak_alloc_points(ctx, Q, mp);
+  if (!rc && (hipMalloc(&dx, sizeof(double) * 3 * (size_t)(np + mp)) != hipSuccess ||
+              hipMalloc(&dK, sizeof(double) * (size_t)np * mp) != hipSuccess ||
+              (D2_host && hipMalloc(&dD2, sizeof(double) * (size_t)np * mp) != hipSuccess))) {
+    ctx->err = "device allocation failed in gpak_compute_k";
+    rc = GPAK_ENOMEM;
+  }
+  if (!rc) {
+    hipStream_t st = ctx->stream;
+    hipMemsetAsync(dx, 0, sizeof(double) * 3 * (size_t)(np + mp), st);
+    double *dx2 = dx + 3 * (size_t)np;
+    for (int k = 0; k < 3; k++) {
+      hipMemcpyAsync(dx + (size_t)k * np, X1 + (size_t)k * n, sizeof(double) * n, hipMemcpyHostToDevice, st);
+      hipMemcpyAsync(dx2 + (size_t)k * mp, X2 + (size_t)k * m, sizeof(double) * m, hipMemcpyHostToDevice, st);
+    }
+    gpak_launch_transform(st, dx, np, n, kp, P);
+    gpak_launch_transform(st, dx2, mp, m, kp, Q);
+    gpak_launch_fill(st, P, Q, np, mp, kp, 1.0, 0.0, 0.0, 0, dK, np, dD2);
+    if (K_host) rc = copy_out(ctx, dK, np, n, m, K_host);
+    if (!rc && D2_host) rc = copy_out(ctx, dD2, np, n, m, D2_host);
+    hipStreamSynchronize(st);
+  }
+  free_points(P); free_points(Q);
+  if (dx) hipFree(dx);
+  if (dK) hipFree(dK);
+  if (dD2) hipFree(dD2);
+  return rc;
+}
+
+int gpak_factor(gpak_ctx *ctx) {
+  if (!ctx) return GPAK_EINVAL;
+  return ensure_factor(ctx);
+}
+
+int gpak_failed_column(const gpak_ctx *ctx) { return ctx ? ctx->failed_col : 0; }
+
+int gpak_get_chol_upper(gpak_ctx *ctx, double *R_host) {
+  if (!ctx || !R_host) return GPAK_EINVAL;
+  int rc = ensure_factor(ctx);
+  if (rc) return rc;
+  const int N = ctx->N;
+  std::vector<double> tmp((size_t)N * N);
+  rc = copy_out(ctx, ctx->dM, ctx->ld, N, N, tmp.data());
+  if (rc) return rc;
+  for (int j = 0; j < N; j++)
+    for (int i = 0; i < N; i++) R_host[i + (size_t)j * N] = i <= j ? tmp[j + (size_t)i * N] : 0.0;  // R = L^T
+  return GPAK_OK;
+}
+
+int gpak_solve_alpha(gpak_ctx *ctx, double *alpha_host) {
+  if (!ctx) return GPAK_EINVAL;
+  int rc = ensure_alpha(ctx);
+  if (rc) return rc;
+  if (alpha_host) {
+    GPAK_HIP(hipMemcpyAsync(alpha_host, ctx->dAlpha, sizeof(double) * ctx->N, hipMemcpyDeviceToHost, ctx->stream));
+    GPAK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return GPAK_OK;
+}
+
+int gpak_solve_chol(gpak_ctx *ctx, double *X_host, int k) {
+  if (!ctx || !X_host || k <= 0) return GPAK_EINVAL;
+  int rc = ensure_factor(ctx);
+  if (rc) return rc;
+  return gpak_solve_chol_impl(ctx, X_host, k);
+}
+
+int gpak_nlz(gpak_ctx *ctx, double *nlz) {
+  if (!ctx || !nlz) return GPAK_EINVAL;
+  int rc = ensure_nlz(ctx);
+  if (rc) {
+    *nlz = std::numeric_limits<double>::quiet_NaN();  // GP_Utils.cpp:1146, 1157
+    return rc;
+  }
+  *nlz = ctx->nlz;
+  return GPAK_OK;
+}
+
+int gpak_nlz_terms(gpak_ctx *ctx, double *quad, double *sumlp, double *logdet) {
+  if (!ctx) return GPAK_EINVAL;
+  int rc = ensure_nlz(ctx);
+  if (rc) return rc;
+  if (quad) *quad = ctx->quad;
+  if (sumlp) *sumlp = ctx->sumlp;
+  if (logdet) *logdet = ctx->logdet;
+  return GPAK_OK;
+}
+
+int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, double *var, int compat_flags) {
+  if (!ctx || !Xte || !mean || M <= 0) return GPAK_EINVAL;
+  if (d != 3) { ctx->err = "HIP path handles 3-D inputs"; return GPAK_ENOTIMPL; }
+  // _postVar calls logLikelihood() (GP_Utils.cpp:980); _postMean calls updateAlpha() (:961)
+  int rc = ensure_nlz(ctx);
+  if (rc) return rc;
+  rc = gpak_predict_impl(ctx, Xte, M, mean, var);
+  if (rc) return rc;
+  if (var) {
+    if (compat_flags & GPAK_COMPAT_VARCLAMP) {
+      // GP_Utils.cpp:1002-1003: `uvec ind = varSigma < 0; varSigma.elem(ind) = 0` -- the 0/1
+      // mask is an index list, so element 0 is zeroed when any entry is >= 0 and element 1
+      // when any entry is < 0.
+      bool any_neg = false, any_nonneg = false;
+      for (long i = 0; i < M; i++) { if (var[i] < 0) any_neg = true; else any_nonneg = true; }
+      if (any_nonneg) var[0] = 0.0;
+      if (any_neg && M > 1) var[1] = 0.0;
+    } else {
+      for (long i = 0; i < M; i++) if (var[i] < 0) var[i] = 0.0;
+    }
+    if (!((compat_flags & GPAK_COMPAT_SN2SKIP) && ctx->sn2 == 1.0))  // GP_Utils.cpp:1036-1040
+      for (long i = 0; i < M; i++) var[i] += ctx->sn2;
+  }
+  return GPAK_OK;
+}
+
+int gpak_grad(gpak_ctx *ctx, double *g) {
+  if (!ctx || !g) return GPAK_EINVAL;
+  int rc = ensure_nlz(ctx);  // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
+  if (rc) return rc;
+  return gpak_grad_impl(ctx, g);
+}
+
+int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out) {
+  if (!ctx || !out) return GPAK_EINVAL;
+  *out = ctx->times;
+  return GPAK_OK;
+}
+
+int gpak_calibrate(gpak_ctx *ctx, double *mfma_f64_tflops, double *hbm_write_gbs) {
+  if (!ctx || !mfma_f64_tflops || !hbm_write_gbs) return GPAK_EINVAL;
+  GPAK_HIP(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)1 << 30;
+  double *scratch = nullptr;
+  if (hipMalloc(&scratch, bytes) != hipSuccess) { ctx->err = "calibration scratch allocation failed"; return GPAK_ENOMEM; }
+  int rc = gpak_calibrate_impl(ctx, scratch, bytes, mfma_f64_tflops, hbm_write_gbs);
+  hipFree(scratch);
+  return rc;
+}
+
+}  // extern "C"

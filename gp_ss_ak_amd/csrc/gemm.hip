@@ -1,0 +1,194 @@
+// gemm.hip -- fp64 MFMA tile kernel  C = beta*C + alpha * A * B^T  for gfx950.
+//
+// This is the arithmetic of LAPACK dpotrf's level-3 part, which the reference reaches
+// through arma::chol (GP_Utils.cpp:881, 903): the trailing-submatrix update
+// (syrk/gemm, alpha=-1, beta=1), the panel triangular solve as a product with the
+// pre-inverted 128x128 diagonal block (alpha=1, beta=0), and the forward substitution
+// with many right-hand sides of _postVar (GP_Utils.cpp:991).
+//
+// Geometry: 128x128 output tile per workgroup, 4 waves (2x2), each wave 64x64 =
+// 4x4 v_mfma_f64_16x16x4_f64 accumulators; K staged 16 deep through double-buffered
+// LDS ([k][row] images, row stride 144 doubles so that the four k-planes a wave reads
+// per fragment land on disjoint bank halves).  All operands are column-major, so a
+// wave's global read of one k-column of a tile is 1 KiB contiguous (16 B per lane).
+//
+// MFMA operand roles are swapped (the B-matrix fragment is the instruction's A operand):
+// the f64 16x16x4 result layout is col=lane&15,row=(lane>>4)+4*reg, so with the swap a
+// lane group writes 16 consecutive matrix rows (128 B) of one column.
+#include "gpak_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define TM 128
+#define TN 128
+#define KB 16
+#define LDS_LD 144
+
+template <bool TRAILING>
+__global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
+                                                            const double *A, long lda, const double *B,
+                                                            long ldb,
+                                                            double beta, double *C, long ldc, int rb0,
+                                                            int cb0, int lower_skip) {
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
+  __shared__ double lds[2][2][KB][LDS_LD];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = w & 1, wc = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  const double *Ag = A + (size_t)ti * TM + 2 * lane;
+  const double *Bg = B + (size_t)tj * TN + 2 * lane;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  double2 ra[4], rb[4];
+  const int nstage = K / KB;
+
+  // prologue: stage 0
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int k = w + 4 * s;
+    ra[s] = *reinterpret_cast<const double2 *>(Ag + (size_t)k * lda);
+    rb[s] = *reinterpret_cast<const double2 *>(Bg + (size_t)k * ldb);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int k = w + 4 * s;
+    *reinterpret_cast<double2 *>(&lds[0][0][k][2 * lane]) = ra[s];
+    *reinterpret_cast<double2 *>(&lds[0][1][k][2 * lane]) = rb[s];
+  }
+  __syncthreads();
+
+  for (int st = 0; st < nstage; st++) {
+    const int buf = st & 1;
+    const bool more = st + 1 < nstage;
+    if (more) {
+      const size_t kb = (size_t)(st + 1) * KB;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const size_t k = kb + w + 4 * s;
+        ra[s] = *reinterpret_cast<const double2 *>(Ag + k * lda);
+        rb[s] = *reinterpret_cast<const double2 *>(Bg + k * ldb);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; kk++) {
+      double a[4], b[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) a[mi] = lds[buf][0][kk * 4 + l4][wr * 64 + mi * 16 + l15];
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++) b[ni] = lds[buf][1][kk * 4 + l4][wc * 64 + ni * 16 + l15];
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int k = w + 4 * s;
+        *reinterpret_cast<double2 *>(&lds[buf ^ 1][0][k][2 * lane]) = ra[s];
+        *reinterpret_cast<double2 *>(&lds[buf ^ 1][1][k][2 * lane]) = rb[s];
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds rows (.. + l15), columns (.. + l4 + 4*reg)
+  double *Cg = C + (size_t)ti * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + l4) * ldc;
+  if (beta == 0.0) {
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = alpha * acc[mi][ni][r];
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++) {
+      double c[4][4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[ni][r] = Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc];
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = fma(alpha, acc[mi][ni][r], beta * c[ni][r]);
+    }
+  }
+}
+
+void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
+                         const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
+                         int col_block0, bool lower_skip, bool trailing) {
+  if (mt <= 0 || nt <= 0) return;
+  dim3 grid(mt, nt), block(256);
+  if (trailing)
+    hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                       row_block0, col_block0, lower_skip ? 1 : 0);
+  else
+    hipLaunchKernelGGL(gpak_gemm_nt_f64<false>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                       row_block0, col_block0, lower_skip ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Calibration microbenchmarks: back-to-back fp64 MFMA issue and a
+// streaming 16-B store, so roofline fractions can be quoted against measured ceilings too.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpak_calib_mfma_f64(double *out, int iters) {
+  d4 acc[8];
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;  // keep the chain live
+}
+
+__global__ __launch_bounds__(256) void gpak_calib_store(double2 *out, size_t n2) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n2; i += stride) out[i] = make_double2(1.0, 2.0);
+}
+
+int gpak_calibrate_impl(gpak_ctx *ctx, double *scratch, size_t scratch_bytes, double *tflops, double *gbs) {
+  hipEvent_t e0, e1;
+  GPAK_HIP(hipEventCreate(&e0));
+  GPAK_HIP(hipEventCreate(&e1));
+  const int iters = 4096, blocks = 256 * 8;
+  hipLaunchKernelGGL(gpak_calib_mfma_f64, dim3(blocks), dim3(256), 0, ctx->stream, scratch, 64);
+  GPAK_HIP(hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL(gpak_calib_mfma_f64, dim3(blocks), dim3(256), 0, ctx->stream, scratch, iters);
+  GPAK_HIP(hipEventRecord(e1, ctx->stream));
+  GPAK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPAK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  size_t n2 = scratch_bytes / 16;
+  hipLaunchKernelGGL(gpak_calib_store, dim3(2048), dim3(256), 0, ctx->stream, (double2 *)scratch, n2);
+  GPAK_HIP(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < 4; r++)
+    hipLaunchKernelGGL(gpak_calib_store, dim3(2048), dim3(256), 0, ctx->stream, (double2 *)scratch, n2);
+  GPAK_HIP(hipEventRecord(e1, ctx->stream));
+  GPAK_HIP(hipEventSynchronize(e1));
+  GPAK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *gbs = 4.0 * (double)(n2 * 16) / (ms * 1e-3) / 1e9;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return GPAK_OK;
+}

@@ -1,0 +1,137 @@
+// gpak_internal.h -- shared declarations of libgpak_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gpak.h"
+
+#define GPAK_TILE 128  // every matrix dimension on the device is padded to this
+
+// Parameters of the fused ExpAns+Bias kernel function, as the device sees them.
+// A = sigInv = Rot * diag(L) * Rot^T   (Kernel.cpp:1399-1425), built on the host.
+struct KernParams {
+  double A[9];   // column-major 3x3
+  double mu[3];  // pooled mean used for centring (Kernel.cpp:1391-1397)
+  double var2;   // Sigma_ExpAns^2   (Kernel.cpp:861)
+  double bias;   // Sigma_Bias       (Kernel.cpp:366)
+  int mode;      // GPAK_DIST_*
+};
+
+// A transformed point set on the device: u = (x - mu) A, SoA, plus |u|^2.
+struct DevPoints {
+  double *u0 = nullptr, *u1 = nullptr, *u2 = nullptr, *s = nullptr;
+  int n = 0;    // valid points
+  int cap = 0;  // allocated points (multiple of GPAK_TILE)
+};
+
+struct gpak_ctx {
+  int device = 0;
+  int precision = GPAK_F64;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // training set
+  int N = 0, Np = 0, ld = 0, d = 0;
+  double *dX = nullptr;      // N x 3 raw coordinates, SoA with stride Np
+  double *dy = nullptr;      // Np (padded with 0)
+  std::vector<double> hX;    // host copy of X (col-major N x d), for pooled means
+  double xsum[3] = {0, 0, 0};
+
+  // parameters
+  bool have_params = false;
+  double expans[8] = {0};
+  double bias = 0, sn2 = 0;
+  int dist_mode = GPAK_DIST_DIRECT;
+  KernParams kp;
+
+  // device state
+  DevPoints U;               // transformed training points
+  double *dM = nullptr;      // Np x ld matrix buffer: B then L (lower)
+  double *dInv = nullptr;    // (Np/128) inverted 128x128 diagonal blocks of L
+  double *dAlpha = nullptr;  // Np
+  double *dWork = nullptr;   // 4*Np scratch vectors
+  double *dRed = nullptr;    // small reduction scratch
+  int *dInfo = nullptr;      // first failing column (1-based) or 0
+  enum { M_NONE, M_B, M_L } mstate = M_NONE;
+  bool alpha_ok = false, nlz_ok = false;
+  int failed_col = 0;
+  double quad = 0, sumlp = 0, logdet = 0, nlz = 0;
+
+  // prediction buffers (grown on demand, kept across calls)
+  DevPoints Upred, Tq;       // train / test-batch points centred on the pooled train+test mean
+  double *dXte = nullptr;    // 3 x pred_cap raw test coordinates (SoA)
+  double *dWt = nullptr;     // pred_cap x Np cross-kernel, test-major (transposed kX)
+  double *dPv = nullptr;     // 2 x pred_cap: mean, sum of squares
+  double *dPart = nullptr;   // 64 x pred_cap partial sums
+  int pred_cap = 0;
+  size_t wt_elems = 0;
+
+  // options
+  bool memoise = false;
+  int nb_outer = 512;
+  bool profile = false;
+
+  // timing
+  gpak_phase_times times;
+  hipEvent_t ev[8];
+  std::vector<hipEvent_t> ev_pool;
+};
+
+#define GPAK_HIP(call)                                                                  \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+      return GPAK_EHIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+// ---- gram.hip ---------------------------------------------------------------------------
+// u = (x - mu) A for n points; x SoA with stride xs.
+void gpak_launch_transform(hipStream_t st, const double *x, int xs, int n, const KernParams &kp,
+                           DevPoints &out);
+// Fill C (rows x cols tile grid, ld) with scale*K(P_i,Q_j) + diag*delta_ij; rows/cols beyond
+// the valid counts get delta_ij. lower_only skips tiles strictly above the diagonal.
+void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, int rows_p, int cols_p,
+                      const KernParams &kp, double scale, double diag, double pad_diag, int lower_only,
+                      double *C, long ld, double *D2out);
+// out_j = sum_i w_i K(P_i, Q_j), j < Q.n   (fused Gram-matvec; K never stored).
+// scratch holds splits * Q.cap doubles.
+int gpak_kmatvec_splits(int nP, int nQ);
+void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, const double *w, const DevPoints &Q,
+                         const KernParams &kp, double *scratch, int splits, double *out);
+void gpak_launch_sum_splits(hipStream_t st, const double *part, int part_ld, int splits, int n, double *out);
+int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap);
+void gpak_pooled_mean(const double *s1, long n, const double *s2, long m, double *mu);
+
+// ---- gemm.hip ---------------------------------------------------------------------------
+// C[mt x nt tiles of 128] = beta*C + alpha * A (m x K) * B (n x K)^T, all column-major.
+// lower_skip: skip tile (ti,tj) when row_block0+ti < col_block0+tj.
+// trailing=true selects the instantiation named gpak_syrk_trailing_f64 (profiling only).
+void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
+                         const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
+                         int col_block0, bool lower_skip, bool trailing);
+
+// ---- potrf.hip --------------------------------------------------------------------------
+// Factor the 128x128 block at A (ld) in place (lower), write its inverse to inv (128x128, ld 128).
+void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info);
+int gpak_potrf_blocked(gpak_ctx *ctx);
+
+// ---- solve.hip --------------------------------------------------------------------------
+// x := L^-1 x ; x := L^-T x  (x has Np entries) using the inverted diagonal blocks.
+// x is consumed (overwritten with intermediate values); the solution is written to out.
+void gpak_launch_trsv_fwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,
+                          double *out);
+void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,
+                          double *out);
+// red[0] = sum log L_ii (i < N)
+void gpak_launch_logdet(hipStream_t st, int N, const double *L, long ld, double *red);
+// red[1] = sum alpha_i * 0.5 f_i ; red[2] = sum lp_i   (GP_Utils.cpp:810, 1159)
+void gpak_launch_nlz_terms(hipStream_t st, int N, const double *y, const double *f, const double *alpha,
+                           double sn2, double *red);
+void gpak_launch_scale(hipStream_t st, int n, const double *in, double s, double *out);
+
+// ---- predict.hip ------------------------------------------------------------------------
+void gpak_predict_release(gpak_ctx *ctx);

@@ -1,0 +1,180 @@
+// predict.hip -- predictive mean / variance and multi-right-hand-side solve_chol for gfx950.
+//
+// Replaces GP_utils::_ComputeK_NewData / _postMean / _postVar (GP_Utils.cpp:943-1004).
+// The reference materialises kX (N x M) and runs two dtrtrs with M right-hand sides; here
+//   mean  = fused Gram-matvec (kX never stored),
+//   var_t = kD - (1/sn2) * | L^-1 k*_t |^2       (one forward substitution, not two),
+// streamed over test batches.  The cross-kernel is kept TEST-MAJOR (Wt = kX^T, batch x N) so
+// that both steps of the blocked forward substitution are the same A*B^T MFMA kernel as the
+// Cholesky:   Wt[:, j] := Wt[:, j] * inv(L_jj)^T ;  Wt[:, rest] -= Wt[:, j] * L[rest, j]^T.
+#include <algorithm>
+#include <cstdlib>
+
+#include "gpak_internal.h"
+
+#define PB 128
+
+// part[split][t] = sum over the split's columns of V[t, c]^2
+__global__ __launch_bounds__(256) void gpak_rowsumsq_part_f64(const double *__restrict__ V, long ldv, int rows,
+                                                               int cols, int cols_per_split,
+                                                               double *__restrict__ part, int part_ld) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows) return;
+  const int c0 = blockIdx.y * cols_per_split;
+  const int c1 = min(cols, c0 + cols_per_split);
+  double s0 = 0.0, s1 = 0.0;
+  int c = c0;
+  for (; c + 1 < c1; c += 2) {
+    double a = V[t + (size_t)c * ldv], b = V[t + (size_t)(c + 1) * ldv];
+    s0 = fma(a, a, s0);
+    s1 = fma(b, b, s1);
+  }
+  if (c < c1) { double a = V[t + (size_t)c * ldv]; s0 = fma(a, a, s0); }
+  part[(size_t)blockIdx.y * part_ld + t] = s0 + s1;
+}
+
+void gpak_predict_release(gpak_ctx *ctx) {
+  if (ctx->Upred.u0) hipFree(ctx->Upred.u0);
+  if (ctx->Tq.u0) hipFree(ctx->Tq.u0);
+  ctx->Upred = DevPoints(); ctx->Tq = DevPoints();
+  if (ctx->dXte) hipFree(ctx->dXte);
+  if (ctx->dWt) hipFree(ctx->dWt);
+  if (ctx->dPv) hipFree(ctx->dPv);
+  if (ctx->dPart) hipFree(ctx->dPart);
+  ctx->dXte = ctx->dWt = ctx->dPv = ctx->dPart = nullptr;
+  ctx->pred_cap = 0; ctx->wt_elems = 0;
+}
+
+static int ensure_predict_bufs(gpak_ctx *ctx, int cap, bool want_var) {
+  if (ctx->pred_cap < cap) {
+    if (ctx->dXte) hipFree(ctx->dXte);
+    if (ctx->dPv) hipFree(ctx->dPv);
+    if (ctx->dPart) hipFree(ctx->dPart);
+    ctx->dXte = ctx->dPv = ctx->dPart = nullptr;
+    if (hipMalloc(&ctx->dXte, sizeof(double) * 3 * (size_t)cap) != hipSuccess ||
+        hipMalloc(&ctx->dPv, sizeof(double) * 2 * (size_t)cap) != hipSuccess ||
+        hipMalloc(&ctx->dPart, sizeof(double) * 64 * (size_t)cap) != hipSuccess) {
+      ctx->err = "device allocation failed for prediction buffers";
+      return GPAK_ENOMEM;
+    }
+    int rc = gpak_alloc_points(ctx, ctx->Tq, cap);
+    if (rc) return rc;
+    ctx->pred_cap = cap;
+  }
+  int rc = gpak_alloc_points(ctx, ctx->Upred, ctx->Np);
+  if (rc) return rc;
+  size_t need = want_var ? (size_t)ctx->pred_cap * ctx->Np : 0;
+  if (need > ctx->wt_elems) {
+    if (ctx->dWt) hipFree(ctx->dWt);
+    ctx->dWt = nullptr; ctx->wt_elems = 0;
+    if (hipMalloc(&ctx->dWt, sizeof(double) * need) != hipSuccess) {
+      ctx->err = "device allocation failed for the cross-kernel batch";
+      return GPAK_ENOMEM;
+    }
+    ctx->wt_elems = need;
+  }
+  return GPAK_OK;
+}
+
+// blocked forward substitution on the test-major batch: Wt (mbp x Np, ld ldw) := Wt * L^-T
+static void forward_subst_batch(gpak_ctx *ctx, double *Wt, long ldw, int mbp) {
+  const int Np = ctx->Np, T = Np / PB;
+  const long ld = ctx->ld;
+  hipStream_t st = ctx->stream;
+  const int mt = mbp / PB;
+  for (int jb = 0; jb < T; jb++) {
+    const size_t j0 = (size_t)jb * PB;
+    const double *inv = ctx->dInv + (size_t)jb * 2 * PB * PB;
+    double *Wj = Wt + j0 * ldw;
+    gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Wj, ldw, inv, PB, 0.0, Wj, ldw, 0, 0, false, false);
+    const int nrest = T - jb - 1;
+    if (nrest > 0)
+      gpak_launch_gemm_nt(st, mt, nrest, PB, -1.0, Wj, ldw, ctx->dM + (j0 + PB) + j0 * ld, ld, 1.0,
+                          Wt + (j0 + PB) * ldw, ldw, 0, 0, false, false);
+  }
+}
+
+int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var) {
+  GPAK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int N = ctx->N, Np = ctx->Np;
+  int batch = 4096;
+  if (const char *e = getenv("GPAK_PRED_BATCH")) batch = std::max(PB, atoi(e) / PB * PB);
+  // keep the cross-kernel batch under ~8 GiB
+  while (batch > PB && (size_t)batch * Np * sizeof(double) > ((size_t)8 << 30)) batch /= 2;
+  long Mp = (M + PB - 1) / PB * PB;
+  const int cap = (int)std::min<long>(Mp, batch);
+  int rc = ensure_predict_bufs(ctx, cap, var != nullptr);
+  if (rc) return rc;
+  hipEvent_t e0 = ctx->ev[5], e1 = ctx->ev[6];
+  GPAK_HIP(hipEventRecord(e0, st));
+
+  // pooled mean over train u (all) test points: Kernel.cpp:1391-1392 with X1 = Xinp, X2 = Xin
+  double s2[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++)
+    for (long i = 0; i < M; i++) s2[k] += Xte[i + (size_t)k * M];
+  KernParams kp = ctx->kp;
+  gpak_pooled_mean(ctx->xsum, N, s2, M, kp.mu);
+  gpak_launch_transform(st, ctx->dX, Np, N, kp, ctx->Upred);
+
+  const double kD = ctx->expans[6] * ctx->expans[6] + ctx->bias;  // diag_Compute, Kernel.cpp:780-783, 328-332
+  double *dMean = ctx->dPv, *dSq = ctx->dPv + cap;
+  std::vector<double> hsq;
+  for (long b0 = 0; b0 < M; b0 += cap) {
+    const int mb = (int)std::min<long>(cap, M - b0);
+    const int mbp = (mb + PB - 1) / PB * PB;
+    GPAK_HIP(hipMemsetAsync(ctx->dXte, 0, sizeof(double) * 3 * (size_t)cap, st));
+    for (int k = 0; k < 3; k++)
+      GPAK_HIP(hipMemcpyAsync(ctx->dXte + (size_t)k * cap, Xte + (size_t)k * M + b0, sizeof(double) * mb,
+                              hipMemcpyHostToDevice, st));
+    gpak_launch_transform(st, ctx->dXte, cap, mb, kp, ctx->Tq);
+    // _postMean: mu_t = Alpha . kX(:,t)
+    int splits = gpak_kmatvec_splits(N, mb);
+    gpak_launch_kmatvec(st, ctx->Upred, ctx->dAlpha, ctx->Tq, kp, ctx->dPart, splits, dMean);
+    GPAK_HIP(hipMemcpyAsync(mean + b0, dMean, sizeof(double) * mb, hipMemcpyDeviceToHost, st));
+    if (var) {
+      const long ldw = cap;
+      gpak_launch_fill(st, ctx->Tq, ctx->Upred, mbp, Np, kp, 1.0, 0.0, 0.0, 0, ctx->dWt, ldw, nullptr);
+      forward_subst_batch(ctx, ctx->dWt, ldw, mbp);
+      int vs = std::max(1, std::min(64, Np / 512));
+      int cps = (Np + vs - 1) / vs;
+      hipLaunchKernelGGL(gpak_rowsumsq_part_f64, dim3((mbp + 255) / 256, vs), dim3(256), 0, st, ctx->dWt, ldw,
+                         mbp, Np, cps, ctx->dPart, cap);
+      gpak_launch_sum_splits(st, ctx->dPart, cap, vs, mb, dSq);
+      hsq.resize(mb);
+      GPAK_HIP(hipMemcpyAsync(hsq.data(), dSq, sizeof(double) * mb, hipMemcpyDeviceToHost, st));
+      GPAK_HIP(hipStreamSynchronize(st));
+      // varSigma = kD - sum(LKs % kX) with LKs = sW . B^-1 . sW kX   (GP_Utils.cpp:985-999)
+      for (int i = 0; i < mb; i++) var[b0 + i] = kD - hsq[i] / ctx->sn2;
+    }
+  }
+  GPAK_HIP(hipEventRecord(e1, st));
+  GPAK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPAK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  ctx->times.predict_ms = ms;
+  return GPAK_OK;
+}
+
+// solve_chol with k right-hand sides held on the host (GP_Utils.cpp:841-845)
+int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k) {
+  GPAK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int N = ctx->N, Np = ctx->Np;
+  double *w0 = ctx->dWork, *w1 = ctx->dWork + Np, *w2 = ctx->dWork + 2 * (size_t)Np;
+  for (int c = 0; c < k; c++) {
+    GPAK_HIP(hipMemsetAsync(w0, 0, sizeof(double) * Np, st));
+    GPAK_HIP(hipMemcpyAsync(w0, X_host + (size_t)c * N, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    gpak_launch_trsv_fwd(st, Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
+    gpak_launch_trsv_bwd(st, Np, ctx->dM, ctx->ld, ctx->dInv, w1, w2);
+    GPAK_HIP(hipMemcpyAsync(X_host + (size_t)c * N, w2, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+  }
+  GPAK_HIP(hipStreamSynchronize(st));
+  return GPAK_OK;
+}
+
+int gpak_grad_impl(gpak_ctx *ctx, double *g) {
+  (void)g;
+  ctx->err = "gpak_grad: reference-style gradient (SURVEY.md 8(f-1)) is not built in this round";
+  return GPAK_ENOTIMPL;
+}

@@ -1,0 +1,149 @@
+/*
+ * gpak.h -- C-ABI of libgpak_hip.so: the MI355X (gfx950) implementation of the
+ * GP_SS_AK hot path (ExpAns+Bias Gram build, Cholesky factor/solve,
+ * log-marginal-likelihood, predictive mean/variance).
+ *
+ * The reference has no FFI layer; its seam is the C++ member interface of
+ * `Kernels` / `GP_utils`.  Each entry point below names the
+ * reference member(s) whose body it replaces.  INTEGRATION.md shows the
+ * binding a maintainer of the reference would add (arma::mat::memptr() in,
+ * memptr() out).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - host matrices are column-major doubles (arma::mat layout), caller-owned,
+ *     never retained after the call returns.
+ *   - every function returns an int status: 0 = GPAK_OK,
+ *     GPAK_ENOTPD = the reference's Chol_fail (GP_Utils.cpp:881-888): callers
+ *     map it to quiet NaN exactly like GP_Utils.cpp:1145-1158;
+ *     negative = HIP runtime failure (text via gpak_last_error()).
+ *   - one ctx = one GPU = one host thread; calls are synchronous on return.
+ *   - there is NO CPU fallback: if no gfx950 device / code object is usable the
+ *     create call fails with GPAK_EHIP.
+ */
+#ifndef GPAK_H
+#define GPAK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpak_ctx gpak_ctx;
+
+/* status codes */
+#define GPAK_OK       0
+#define GPAK_ENOTPD   1   /* B = I + K/sn2 not positive definite (Chol_fail)            */
+#define GPAK_EINVAL   2   /* bad argument                                                */
+#define GPAK_ESTATE   3   /* call out of order (e.g. no training set yet)                */
+#define GPAK_ENOMEM   4   /* device allocation failed                                    */
+#define GPAK_ENOTIMPL 5   /* feature not built yet (e.g. precision f32)                  */
+#define GPAK_EHIP    (-1) /* HIP runtime error                                           */
+
+/* precision of the device arithmetic (fixed at ctx creation) */
+#define GPAK_F64 0
+#define GPAK_F32 1
+
+/* distance formulation inside MahaDist (Kernel.cpp:1370-1435) */
+#define GPAK_DIST_EXPANSION 0 /* |u|^2+|v|^2-2u.v, pooled-mean centred, clamped at 0 (as written) */
+#define GPAK_DIST_DIRECT    1 /* |(x_i-x_j)A|^2: same quantity, no cancellation noise (default)    */
+
+/* predictive-variance compatibility flags */
+#define GPAK_COMPAT_VARCLAMP 1 /* GP_Utils.cpp:1002-1003: 0/1 mask used as an index list */
+#define GPAK_COMPAT_SN2SKIP  2 /* GP_Utils.cpp:1036-1040: "+sn2" skipped when sn2 == 1.0 */
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+/* device = HIP device ordinal. */
+int  gpak_create(gpak_ctx **out, int device, int precision);
+void gpak_destroy(gpak_ctx *ctx);
+const char *gpak_last_error(const gpak_ctx *ctx);
+/* library-level error text for failures that happen before a ctx exists */
+const char *gpak_global_error(void);
+
+/* ---- model state ------------------------------------------------------------------------ */
+/* GP_utils ctor / test-time reload: members Xinp (N x d) and yTarg (N x 1)
+ * (GP_Utils.cpp:9-46, gp_ss_ak.cpp:384-395).  d must be 3 on the HIP path. */
+int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d);
+
+/* GP_utils::set_GP_Pars (GP_Utils.cpp:130-157): expans[8] in the reference's order
+ * {AngleX, inverseWidthx, AngleY, inverseWidthy, AngleZ, inverseWidthz, Sigma, InversewidthR}
+ * (Kernel.cpp:737-761), Kern_Bias Sigma_Bias (Kernel.cpp:317-320), hyperlf(0)=sn2 used raw
+ * (GP_Utils.cpp:405-406).  Like the reference, every call invalidates K, L and alpha
+ * (GP_Utils.cpp:132-133) -- unless `memoise` was enabled with gpak_set_option and the
+ * values are bit-identical to the previous call. */
+int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2, int dist_mode);
+
+#define GPAK_OPT_MEMOISE   1  /* value-based dirty tracking instead of always-invalidate   */
+#define GPAK_OPT_NB_OUTER  2  /* outer Cholesky block width (multiple of 128)              */
+#define GPAK_OPT_PROFILE   3  /* 1: bracket each trailing-update launch with hip events    */
+int gpak_set_option(gpak_ctx *ctx, int option, long value);
+
+/* ---- hot path --------------------------------------------------------------------------- */
+/* HybKerns::computeK(Xinp, Xinp, K, D2) over {ExpAns, Bias} (Kernel.cpp:140-154, 856-882,
+ * 362-367, MahaDist :1370-1435).  K_host (N x N) and D2_host (N x N) may each be NULL. */
+int gpak_gram(gpak_ctx *ctx, double *K_host, double *D2_host);
+
+/* Kernels::computeK(X1, X2, K, D2) for arbitrary point sets with the ctx's parameters
+ * (the GP_utils::_ComputeK_NewData call, GP_Utils.cpp:943-949, is X1 = Xinp). */
+int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int m, int d,
+                   double *K_host, double *D2_host);
+
+/* GP_utils::ldB2_exact (GP_Utils.cpp:872-915): B = I + (sW sW') % K, chol(B).
+ * The factor is kept on the device as the LOWER factor L = R^T of arma::chol's upper R. */
+int gpak_factor(gpak_ctx *ctx);
+/* copy the factor out as arma::chol would return it in GP_utils::Lchol: R upper, N x N */
+int gpak_get_chol_upper(gpak_ctx *ctx, double *R_host);
+/* failing column (1-based) of the last GPAK_ENOTPD, 0 if none */
+int gpak_failed_column(const gpak_ctx *ctx);
+
+/* GP_utils::updateAlpha / irls (GP_Utils.cpp:191-228, 383-393) for the Gaussian likelihood:
+ * alpha = (K + sn2 I)^-1 y, obtained with one factorisation and two triangular solves
+ * (the IRLS fixed point).  alpha_host (N) may be NULL. */
+int gpak_solve_alpha(gpak_ctx *ctx, double *alpha_host);
+
+/* GP_utils::solve_chol(Lchol, Xr, dB) (GP_Utils.cpp:841-845): X := R^-1 R^-T X, X is N x k. */
+int gpak_solve_chol(gpak_ctx *ctx, double *X_host, int k);
+
+/* GP_utils::logLikelihood (GP_Utils.cpp:1138-1162): runs gram/factor/solve if dirty.
+ * On GPAK_ENOTPD *nlz is quiet NaN (GP_Utils.cpp:1145-1146, 1155-1158). */
+int gpak_nlz(gpak_ctx *ctx, double *nlz);
+/* the three terms of GP_Utils.cpp:1159:  quad = Alpha' (0.5 f), sumlp = accu(lp), logdet */
+int gpak_nlz_terms(gpak_ctx *ctx, double *quad, double *sumlp, double *logdet);
+
+/* GP_utils::posteriorMeanVar (GP_Utils.cpp:1016-1043) = _ComputeK_NewData + _postMean +
+ * _postVar (:943-1004).  Xte is M x d col-major; mean (M) required, var (M) may be NULL.
+ * Test points are streamed in batches; the N x M cross-kernel is never materialised. */
+int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, double *var,
+                 int compat_flags);
+
+/* GP_utils::GradLL (GP_Utils.cpp:1171-1262) with Kern_ExpAnisotropic::getGradients
+ * (Kernel.cpp:886-1263) and Kern_Bias::getGradients (:370-377), reference formulas as
+ * written; g[10] = {8 ExpAns, bias, sn2}. */
+int gpak_grad(gpak_ctx *ctx, double *g);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+typedef struct {
+  double gram_ms;      /* fused fill of B = I + K/sn2 (lower tiles)                      */
+  double factor_ms;    /* whole blocked Cholesky                                         */
+  double solve_ms;     /* two triangular solves                                          */
+  double nlz_ms;       /* f = K alpha (fused Gram-matvec), lp, reductions                */
+  double predict_ms;   /* last gpak_predict                                              */
+  double grad_ms;      /* last gpak_grad                                                 */
+  /* trailing-update kernel (the dominant, MFMA-bound launch), last factorisation,
+   * measured with hipEvents on the ctx stream when GPAK_OPT_PROFILE is set: */
+  double trailing_ms;        /* sum of launch durations                                  */
+  double trailing_flops;     /* algorithmic flops of those launches (lower tiles only)   */
+  int    trailing_launches;
+  /* fused fill kernel: bytes it must write */
+  double gram_bytes;
+  int    n;                  /* N                                                        */
+  int    n_padded;           /* N rounded up to the 128-tile                             */
+} gpak_phase_times;
+int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out);
+
+/* fp64-MFMA and HBM-write calibration microbenchmarks */
+int gpak_calibrate(gpak_ctx *ctx, double *mfma_f64_tflops, double *hbm_write_gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPAK_H */

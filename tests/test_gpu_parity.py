@@ -1,0 +1,93 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64): north_star asks for 1e-5 relative on nlZ / predictive mean / variance
+against the Armadillo CPU path.  The tests hold the HIP path to far tighter bounds against
+the oracle; each bound is written next to its assert.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from gp_ss_ak_amd import gpak, synth
+
+pytestmark = pytest.mark.gpu
+
+E = np.array(synth.DEFAULT_EXPANS)
+BIAS, SN2 = synth.DEFAULT_BIAS, synth.DEFAULT_SN2
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+@pytest.mark.parametrize("N", [8, 64, 200, 512, 1000])
+@pytest.mark.parametrize("mode", [gpak.DIST_DIRECT, gpak.DIST_EXPANSION])
+def test_gram_matches_oracle(gp, orc, N, mode):
+    X, y = synth.drillholes(N)
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, mode)
+    K, D2 = gp.gram(want_d2=True)
+    Ko, D2o = orc.gram(X, X, E, BIAS, mode, want_d2=True)
+    if mode == gpak.DIST_DIRECT:
+        # same arithmetic up to fma contraction and the exp/sqrt implementations
+        assert np.abs(D2 - D2o).max() <= 1e-14
+        assert rel(K, Ko) <= 1e-13
+        assert np.all(K.diagonal() == E[6] ** 2 + BIAS)  # K_ii = sigma^2 + bias exactly
+    else:
+        # expansion form: cancellation noise ~1e-15 in D2 becomes ~3e-8 in K near D2 = 0
+        assert np.abs(D2 - D2o).max() <= 1e-13
+        assert rel(K, Ko) <= 2e-7
+    assert np.array_equal(K, K.T)
+
+
+@pytest.mark.parametrize("N", [8, 64, 200, 512, 1000, 2048])
+def test_factor_alpha_nlz_match_oracle(gp, orc, N):
+    X, y = synth.drillholes(N)
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    Ko = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+    info, alpha_o, Lo = orc.nlz_refseq(Ko, y, SN2)  # the reference's IRLS/Brent sequence
+    assert gp.factor()
+    R = gp.chol_upper()
+    assert np.allclose(np.triu(R), R)
+    assert rel(R.T, Lo) <= 1e-11                       # factor of B = I + K/sn2
+    B = np.eye(N) + Ko / SN2
+    assert rel(R.T @ R, B) <= 1e-13                    # R'R = B residual
+    alpha = gp.solve_alpha()
+    assert rel(alpha, alpha_o) <= 1e-8                 # cond(B) ~ 1e3..1e5 times eps, IRLS tol 1e-6 on psi
+    nlz = gp.logLikelihood()
+    assert abs(nlz - info.nlz) <= 1e-9 * abs(info.nlz)
+    q, slp, ld = gp.nlz_terms()
+    assert abs(ld - info.logdet) <= 1e-11 * abs(info.logdet)
+    assert abs(q - info.quad) <= 1e-9 * abs(info.quad)
+    assert abs(slp - info.sumlp) <= 1e-9 * abs(info.sumlp)
+
+
+@pytest.mark.parametrize("N,M", [(64, 16), (512, 16), (1000, 300)])
+def test_predict_matches_oracle(gp, orc, N, M):
+    X, y = synth.drillholes(N)
+    Xte = synth.test_points(M)
+    for mode in (gpak.DIST_DIRECT, gpak.DIST_EXPANSION):
+        gp.set_train(X, y)
+        gp.set_params(E, BIAS, SN2, mode)
+        Ko = orc.gram(X, X, E, BIAS, mode)
+        info, alpha_o, Lo = orc.nlz_lean(Ko, y, SN2)
+        for compat in (0, gpak.COMPAT_VARCLAMP | gpak.COMPAT_SN2SKIP):
+            mean, var = gp.posteriorMeanVar(Xte, compat=compat)
+            mo, vo = orc.predict(X, Xte, E, BIAS, SN2, alpha_o, Lo, mode, compat)
+            assert rel(mean, mo) <= 1e-8
+            assert rel(var, vo) <= 1e-8
+            if compat & gpak.COMPAT_VARCLAMP:
+                assert var[0] == SN2  # Q3: element 0 is always "clamped"
+
+
+def test_not_positive_definite_reports_chol_fail(gp):
+    X, y = synth.drillholes(64)
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, -0.5, gpak.DIST_DIRECT)  # negative noise -> B indefinite
+    assert not gp.factor()
+    assert gp.failed_column() >= 1
+    assert math.isnan(gp.logLikelihood())            # GP_Utils.cpp:1145-1146
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)    # and the context recovers
+    assert gp.factor()
