@@ -76,8 +76,12 @@ def test_predict_matches_oracle(gp, orc, N, M):
         for compat in (0, gpak.COMPAT_VARCLAMP | gpak.COMPAT_SN2SKIP):
             mean, var = gp.posteriorMeanVar(Xte, compat=compat)
             mo, vo = orc.predict(X, Xte, E, BIAS, SN2, alpha_o, Lo, mode, compat)
-            assert rel(mean, mo) <= 1e-8
-            assert rel(var, vo) <= 1e-8
+            # direct mode: same arithmetic up to rounding.  expansion mode: the 1e-15 cancellation
+            # noise of D2 (3e-8 in K near D2=0) is implementation-defined and is amplified by
+            # cond(K + sn2 I) in alpha; 1e-5 is north_star's bound.
+            tol = 1e-8 if mode == gpak.DIST_DIRECT else 1e-5
+            assert rel(mean, mo) <= tol
+            assert rel(var, vo) <= tol
             if compat & gpak.COMPAT_VARCLAMP:
                 assert var[0] == SN2  # Q3: element 0 is always "clamped"
 
