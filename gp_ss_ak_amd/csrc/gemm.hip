@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
   const int wr = w & 1, wc = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  const double *Ag = A + (size_t)ti * TM + 2 * lane;
+  const double *Ag = A + (size_t)ti * TM + 2 * lane;  // per-lane source of a 16-B piece
   const double *Bg = B + (size_t)tj * TN + 2 * lane;
 
   d4 acc[4][4];
@@ -46,36 +46,31 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
 #pragma unroll
     for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  double2 ra[4], rb[4];
   const int nstage = K / KB;
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
 
-  // prologue: stage 0
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const int k = w + 4 * s;
-    ra[s] = *reinterpret_cast<const double2 *>(Ag + (size_t)k * lda);
-    rb[s] = *reinterpret_cast<const double2 *>(Bg + (size_t)k * ldb);
+  // Direct-to-LDS staging: one global_load_lds_dwordx4 per wave writes one k-row of a tile
+  // (64 lanes x 16 B = 128 doubles = 1 KiB contiguous in global memory AND in LDS).
+  // Wave w stages k-rows w, w+4, w+8, w+12 of both operands: 8 instructions per stage.
+#define GPAK_STAGE(buf_, kbase_)                                                                  \
+  _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                 \
+    const size_t k_ = (size_t)(kbase_) + w + 4 * s;                                               \
+    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + k_ * lda), (lptr_t)&lds[buf_][0][w + 4 * s][0], \
+                                     16, 0, 0);                                                   \
+    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + k_ * ldb), (lptr_t)&lds[buf_][1][w + 4 * s][0], \
+                                     16, 0, 0);                                                   \
   }
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const int k = w + 4 * s;
-    *reinterpret_cast<double2 *>(&lds[0][0][k][2 * lane]) = ra[s];
-    *reinterpret_cast<double2 *>(&lds[0][1][k][2 * lane]) = rb[s];
-  }
-  __syncthreads();
+
+  GPAK_STAGE(0, 0)
+  __syncthreads();  // emits vmcnt(0) for the in-flight LDS-DMA, then the barrier
 
   for (int st = 0; st < nstage; st++) {
     const int buf = st & 1;
-    const bool more = st + 1 < nstage;
-    if (more) {
-      const size_t kb = (size_t)(st + 1) * KB;
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const size_t k = kb + w + 4 * s;
-        ra[s] = *reinterpret_cast<const double2 *>(Ag + k * lda);
-        rb[s] = *reinterpret_cast<const double2 *>(Bg + k * ldb);
-      }
-    }
+    // stage st+1 streams into the other buffer while this stage's MFMAs run; the last
+    // iteration re-stages its own k-block (clamped, unused) to keep the loop branch-free
+    const int nx = (st + 1 < nstage) ? st + 1 : st;
+    GPAK_STAGE(buf ^ 1, (size_t)nx * KB)
 #pragma unroll
     for (int kk = 0; kk < KB / 4; kk++) {
       double a[4], b[4];
@@ -89,16 +84,13 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
         for (int ni = 0; ni < 4; ni++)
           acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
     }
-    if (more) {
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const int k = w + 4 * s;
-        *reinterpret_cast<double2 *>(&lds[buf ^ 1][0][k][2 * lane]) = ra[s];
-        *reinterpret_cast<double2 *>(&lds[buf ^ 1][1][k][2 * lane]) = rb[s];
-      }
-    }
+    // keep this stage's MFMAs ABOVE the wait+barrier: without the fence hipcc reads all
+    // fragments up front and sinks 61 of the 64 MFMAs below the barrier, so every wave sits
+    // out the full LDS-DMA latency before it computes
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
+#undef GPAK_STAGE
 
   // epilogue: lane holds rows (.. + l15), columns (.. + l4 + 4*reg)
   double *Cg = C + (size_t)ti * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + l4) * ldc;

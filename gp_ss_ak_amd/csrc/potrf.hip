@@ -14,80 +14,182 @@
 #include "gpak_internal.h"
 
 #define PB 128
-#define PLD 129  // LDS leading dimension (odd: row and column walks are both conflict-free)
+#define PLD 132   // LDS leading dimension of the 128x128 block
+#define DLD 17    // leading dimension of the 16x16 inverse blocks
 
-// One workgroup factors the 128x128 block in LDS.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double gpak_rdlane(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// One workgroup (4 waves) factors the 128x128 block held in LDS, 16 columns at a time:
+//   wave 0   : 16x16 diagonal block in registers (one row per lane, pivots broadcast with
+//              v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps) and its 16x16 inverse
+//   all waves: panel  P := P * inv(D)^T  and trailing update  C -= P P^T  on
+//              v_mfma_f64_16x16x4_f64 with operands read from LDS
+// then the 128x128 inverse by block forward substitution, one block column per wave pass:
+// a finished 16x16 accumulator tile is used directly as the B operand of the next MFMA
+// (the f64 16x16x4 D layout row=(lane>>4)+4*reg, col=lane&15 is the B-fragment layout of
+// k-step `reg`), so the inverse never goes back through LDS.
 //   A      : block in global memory (column-major, ld); lower triangle is read
 //   inv    : 2 x (128x128) doubles: inv(L) then inv(L)^T, column-major ld 128
 //   col0   : global column of the block (for the not-positive-definite report)
-//   info   : *info = min(*info or INT_MAX, first failing column 1-based)
+//   info   : atomicMin of the first failing column (1-based)
 __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv,
                                                           int col0, int *info) {
   __shared__ double S[PB * PLD];
-  const int t = threadIdx.x;
-  // load (full block; the upper part is ignored by the algorithm)
+  __shared__ double Dinv[8][16 * DLD];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double *invT = inv + PB * PB;
+
   for (int e = t; e < PB * PB; e += 256) {
     int r = e & (PB - 1), c = e >> 7;
     S[r + c * PLD] = A[r + (size_t)c * ld];
+    // strictly-upper 16x16 tiles of both inverse images are zero (the GEMMs read them)
+    if ((r >> 4) < (c >> 4)) { inv[r + c * PB] = 0.0; invT[c + r * PB] = 0.0; }
   }
   __syncthreads();
 
-  const int i = t & (PB - 1), half = t >> 7;
-  for (int j = 0; j < PB; j++) {
-    double piv = S[j + j * PLD];
-    if (!(piv > 0.0)) {
-      if (t == 0) atomicMin(info, col0 + j + 1);
-      piv = 1.0;  // keep going with finite numbers; the host reports the failure
-    }
-    const double ljj = sqrt(piv);
-    const double rinv = 1.0 / ljj;
-    __syncthreads();  // everyone has read the pivot
-    if (half == 0) {
-      if (i == j) S[j + j * PLD] = ljj;
-      else if (i > j) S[i + j * PLD] *= rinv;
+  for (int kb = 0; kb < 8; kb++) {
+    const int c0 = 16 * kb;
+    if (w == 0) {
+      // ---- (a) diagonal block: row l15 of the block per lane (lanes 16..63 mirror 0..15)
+      double a[16], rinv[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) a[k] = S[(c0 + k) * PLD + c0 + l15];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        double d = gpak_rdlane(a[j], j);
+        if (!(d > 0.0)) {
+          if (lane == 0) atomicMin(info, col0 + c0 + j + 1);
+          d = 1.0;
+        }
+        double r = __builtin_amdgcn_rsq(d);
+        double h = d * r;
+        double e = fma(-h, r, 1.0);
+        r = fma(r * 0.5, e, r);
+        h = d * r;
+        e = fma(-h, r, 1.0);
+        r = fma(r * 0.5, e, r);       // r = d^-1/2
+        double ljj = d * r;
+        ljj = fma(fma(-ljj, ljj, d) * 0.5, r, ljj);  // sqrt(d), one correction
+        rinv[j] = r;
+        a[j] = (l15 == j) ? ljj : a[j] * r;
+#pragma unroll
+        for (int k = j + 1; k < 16; k++) {
+          double lk = gpak_rdlane(a[j], k);
+          a[k] = fma(-a[j], lk, a[k]);
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) S[(c0 + k) * PLD + c0 + l15] = (k <= l15) ? a[k] : 0.0;
+      }
+      // inverse of the 16x16 block: lane c solves L x = e_c
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        double s = (l15 == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) s = fma(-gpak_rdlane(a[k], i), x[k], s);
+        x[i] = s * rinv[i];
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) Dinv[kb][l15 * DLD + i] = x[i];   // X[i][c=l15]
+      }
     }
     __syncthreads();
-    // trailing update: S[i][k] -= l_i * l_k for j < k <= i ; thread handles row i, every
-    // second column
-    if (i > j) {
-      const double li = S[i + j * PLD];
-      for (int k = j + 1 + half; k <= i; k += 2) S[i + k * PLD] -= li * S[k + j * PLD];
+    const int nt = 7 - kb;  // 16-row tiles below the diagonal block
+    // ---- (b) panel tiles: P := P * inv(D)^T  (a tile depends only on itself: no barrier inside)
+    for (int tt = w; tt < nt; tt += 4) {
+      const int r0 = c0 + 16 + 16 * tt;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        double pa = S[(c0 + 4 * s + l4) * PLD + r0 + l15];
+        double xb = Dinv[kb][(4 * s + l4) * DLD + l15];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, xb, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) S[(c0 + l15) * PLD + r0 + l4 + 4 * r] = acc[r];
     }
-    // (next iteration's first barrier orders these writes before anyone's column scaling;
-    //  the pivot read above is of S[j+1][j+1], written only by thread row j+1 -> needs a barrier)
+    __syncthreads();
+    // ---- (c) trailing update of the lower tiles: C(ti,tj) -= P_ti * P_tj^T
+    const int ntile = nt * (nt + 1) / 2;
+    for (int q = w; q < ntile; q += 4) {
+      int ti = 0, rem = q;
+      while (rem > ti) { rem -= ti + 1; ti++; }  // q -> (ti, tj=rem), tj <= ti
+      const int ri = c0 + 16 + 16 * ti, rj = c0 + 16 + 16 * rem;
+      d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = S[(rj + l15) * PLD + ri + l4 + 4 * r];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        double pa = -S[(c0 + 4 * s + l4) * PLD + ri + l15];
+        double pb = S[(c0 + 4 * s + l4) * PLD + rj + l15];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) S[(rj + l15) * PLD + ri + l4 + 4 * r] = acc[r];
+    }
     __syncthreads();
   }
 
-  // write L (upper part of the block zeroed so the stored matrix is cleanly lower)
+  // L out (upper part of the block zeroed so the stored matrix is cleanly lower)
   for (int e = t; e < PB * PB; e += 256) {
     int r = e & (PB - 1), c = e >> 7;
     A[r + (size_t)c * ld] = r >= c ? S[r + c * PLD] : 0.0;
   }
-  __syncthreads();
 
-  // in-place inverse of the lower-triangular block (LAPACK dtrti2 'L' order: last column first)
-  for (int j = PB - 1; j >= 0; j--) {
-    const double ajj = 1.0 / S[j + j * PLD];
-    double y = 0.0;
-    if (half == 0 && i > j) {
-      for (int k = j + 1; k <= i; k++) y += S[i + k * PLD] * S[k + j * PLD];
+  // 128x128 inverse, block column c per wave pass: X_cc = inv(D_c),
+  // X_rc = -inv(D_r) * sum_{k=c..r-1} L_rk X_kc
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int c = pass ? 7 - w : w;
+    d4 Xt[8];
+#pragma unroll
+    for (int s = 0; s < 4; s++) Xt[0][s] = Dinv[c][l15 * DLD + l4 + 4 * s];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int row = 16 * c + l4 + 4 * s, col = 16 * c + l15;
+      const double v = row >= col ? Xt[0][s] : 0.0;
+      inv[row + col * PB] = v;
+      invT[col + row * PB] = v;
     }
-    __syncthreads();
-    if (half == 0) {
-      if (i == j) S[j + j * PLD] = ajj;
-      else if (i > j) S[i + j * PLD] = -ajj * y;
+#pragma unroll
+    for (int rr = 1; rr < 8; rr++) {
+      if (c + rr <= 7) {
+        const int r = c + rr;
+        d4 G = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < rr; m++) {
+          const int k0 = 16 * (c + m);
+#pragma unroll
+          for (int s = 0; s < 4; s++) {
+            double la = S[(k0 + 4 * s + l4) * PLD + 16 * r + l15];
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(la, Xt[m][s], G, 0, 0, 0);
+          }
+        }
+        d4 Xn = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          double da = -Dinv[r][(4 * s + l4) * DLD + l15];
+          Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(da, G[s], Xn, 0, 0, 0);
+        }
+        Xt[rr] = Xn;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int row = 16 * r + l4 + 4 * s, col = 16 * c + l15;
+          inv[row + col * PB] = Xn[s];
+          invT[col + row * PB] = Xn[s];
+        }
+      }
     }
-    __syncthreads();
-  }
-  double *invT = inv + PB * PB;
-  for (int e = t; e < PB * PB; e += 256) {
-    int r = e & (PB - 1), c = e >> 7;
-    double v = r >= c ? S[r + c * PLD] : 0.0;
-    inv[r + c * PB] = v;
-  }
-  for (int e = t; e < PB * PB; e += 256) {
-    int r = e & (PB - 1), c = e >> 7;  // invT[r][c] = inv[c][r]
-    invT[r + c * PB] = c >= r ? S[c + r * PLD] : 0.0;
   }
 }
 
