@@ -107,7 +107,12 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   ctx->device = device;
   ctx->precision = precision;
   memset(&ctx->times, 0, sizeof(ctx->times));
-  if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) { g_global_err = hipGetErrorString(e); delete ctx; return GPAK_EHIP; }
+  int prio_lo = 0, prio_hi = 0;
+  hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
+  if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&ctx->stream_hi, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
+    g_global_err = hipGetErrorString(e); delete ctx; return GPAK_EHIP;
+  }
   for (int i = 0; i < 8; i++) hipEventCreate(&ctx->ev[i]);
   hipMalloc(&ctx->dRed, sizeof(double) * 64);
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
@@ -127,6 +132,8 @@ void gpak_destroy(gpak_ctx *ctx) {
   if (ctx->dInfo) hipFree(ctx->dInfo);
   for (int i = 0; i < 8; i++) hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  for (auto e : ctx->ev_sync) hipEventDestroy(e);
+  hipStreamDestroy(ctx->stream_hi);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -142,6 +149,7 @@ int gpak_set_option(gpak_ctx *ctx, int option, long value) {
       ctx->nb_outer = (int)value;
       return GPAK_OK;
     case GPAK_OPT_PROFILE: ctx->profile = value != 0; return GPAK_OK;
+    case GPAK_OPT_LOOKAHEAD: ctx->lookahead = value != 0; return GPAK_OK;
   }
   ctx->err = "unknown option";
   return GPAK_EINVAL;

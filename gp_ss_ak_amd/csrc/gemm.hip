@@ -15,6 +15,8 @@
 // MFMA operand roles are swapped (the B-matrix fragment is the instruction's A operand):
 // the f64 16x16x4 result layout is col=lane&15,row=(lane>>4)+4*reg, so with the swap a
 // lane group writes 16 consecutive matrix rows (128 B) of one column.
+#include <cstdlib>
+
 #include "gpak_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -29,9 +31,33 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
                                                             const double *A, long lda, const double *B,
                                                             long ldb,
                                                             double beta, double *C, long ldc, int rb0,
-                                                            int cb0, int lower_skip) {
-  const int ti = blockIdx.x, tj = blockIdx.y;
-  if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
+                                                            int cb0, int lower_skip, int mt, int nt) {
+  // Workgroup -> tile map, XCD-aware: the dispatcher deals consecutive workgroup ids round-robin
+  // over the 8 XCDs, so id b runs on XCD (b & 7) as that XCD's (b >> 3)-th workgroup.  Each XCD
+  // walks 8x8 super-tiles: the 64 workgroups resident on its 32 CUs (2 per CU) cover one
+  // super-tile and stream the SAME 8 A-row and 8 B-row panels k-slice by k-slice, so the XCD's
+  // 4 MiB L2 serves 7 of every 8 operand reads (placement only affects speed, never results).
+  int ti, tj;
+  {
+    const int b = blockIdx.x, q = b >> 3;
+    const int slot = q & 63;
+    const int ssel = (q >> 6) * 8 + (b & 7);
+    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
+    int si, sj = 0;
+    if (lower_skip) {
+      int rem = ssel;
+      while (sj < SC && rem >= SR - sj) { rem -= SR - sj; sj++; }
+      si = sj + rem;
+    } else {
+      sj = ssel / SR;
+      si = ssel - sj * SR;
+    }
+    if (sj >= SC) return;
+    ti = si * 8 + (slot & 7);
+    tj = sj * 8 + (slot >> 3);
+    if (ti >= mt || tj >= nt) return;
+    if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
+  }
   __shared__ double lds[2][2][KB][LDS_LD];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = w & 1, wc = w >> 1;
@@ -65,36 +91,36 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
   GPAK_STAGE(0, 0)
   __syncthreads();  // emits vmcnt(0) for the in-flight LDS-DMA, then the barrier
 
-  for (int st = 0; st < nstage; st++) {
+#define GPAK_COMPUTE(buf_)                                                                          \
+  _Pragma("unroll") for (int kk = 0; kk < KB / 4; kk++) {                                           \
+    double a[4], b[4];                                                                              \
+    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                \
+        a[mi] = lds[buf_][0][kk * 4 + l4][wr * 64 + mi * 16 + l15];                                 \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                                \
+        b[ni] = lds[buf_][1][kk * 4 + l4][wc * 64 + ni * 16 + l15];                                 \
+    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                            \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0); \
+  }
+
+  for (int st = 0; st + 1 < nstage; st++) {
     const int buf = st & 1;
-    // stage st+1 streams into the other buffer while this stage's MFMAs run; the last
-    // iteration re-stages its own k-block (clamped, unused) to keep the loop branch-free
-    const int nx = (st + 1 < nstage) ? st + 1 : st;
-    GPAK_STAGE(buf ^ 1, (size_t)nx * KB)
-#pragma unroll
-    for (int kk = 0; kk < KB / 4; kk++) {
-      double a[4], b[4];
-#pragma unroll
-      for (int mi = 0; mi < 4; mi++) a[mi] = lds[buf][0][kk * 4 + l4][wr * 64 + mi * 16 + l15];
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++) b[ni] = lds[buf][1][kk * 4 + l4][wc * 64 + ni * 16 + l15];
-#pragma unroll
-      for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
-    }
+    // stage st+1 streams into the other buffer while this stage's MFMAs run
+    GPAK_STAGE(buf ^ 1, (size_t)(st + 1) * KB)
+    GPAK_COMPUTE(buf)
     // keep this stage's MFMAs ABOVE the wait+barrier: without the fence hipcc reads all
     // fragments up front and sinks 61 of the 64 MFMAs below the barrier, so every wave sits
     // out the full LDS-DMA latency before it computes
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
-#undef GPAK_STAGE
 
-  // epilogue: lane holds rows (.. + l15), columns (.. + l4 + 4*reg)
+  // last stage: no more staging; the C tile (beta != 0) is fetched underneath its MFMAs
+  // lane holds rows (.. + l15), columns (.. + l4 + 4*reg)
   double *Cg = C + (size_t)ti * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + l4) * ldc;
+  const int lbuf = (nstage - 1) & 1;
   if (beta == 0.0) {
+    GPAK_COMPUTE(lbuf)
 #pragma unroll
     for (int mi = 0; mi < 4; mi++)
 #pragma unroll
@@ -103,6 +129,9 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
         for (int r = 0; r < 4; r++)
           Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = alpha * acc[mi][ni][r];
   } else {
+    GPAK_COMPUTE(lbuf)
+    // read-modify-write of the C tile, 16 rows x 64 columns of the wave's sub-tile at a time
+    // (registers for more than one row group in flight do not exist at 2 waves per SIMD)
 #pragma unroll
     for (int mi = 0; mi < 4; mi++) {
       double c[4][4];
@@ -117,19 +146,28 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
           Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = fma(alpha, acc[mi][ni][r], beta * c[ni][r]);
     }
   }
+#undef GPAK_STAGE
+#undef GPAK_COMPUTE
 }
 
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
                          int col_block0, bool lower_skip, bool trailing) {
   if (mt <= 0 || nt <= 0) return;
-  dim3 grid(mt, nt), block(256);
+  const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
+  long nsuper = 0;
+  if (lower_skip) {
+    for (int sj = 0; sj < SC && sj < SR; sj++) nsuper += SR - sj;
+  } else {
+    nsuper = (long)SR * SC;
+  }
+  dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   if (trailing)
     hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt);
   else
     hipLaunchKernelGGL(gpak_gemm_nt_f64<false>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -29,7 +29,8 @@ struct DevPoints {
 struct gpak_ctx {
   int device = 0;
   int precision = GPAK_F64;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;     // main stream: fill, bulk trailing updates, solves
+  hipStream_t stream_hi = nullptr;  // high-priority stream: panel factorisation (look-ahead)
   std::string err;
 
   // training set
@@ -72,11 +73,13 @@ struct gpak_ctx {
   bool memoise = false;
   int nb_outer = 512;
   bool profile = false;
+  bool lookahead = true;
 
   // timing
   gpak_phase_times times;
   hipEvent_t ev[8];
-  std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_pool;   // timing events around the trailing updates
+  std::vector<hipEvent_t> ev_sync;   // cross-stream dependencies of the look-ahead pipeline
 };
 
 #define GPAK_HIP(call)                                                                  \

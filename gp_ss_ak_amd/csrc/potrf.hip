@@ -14,8 +14,6 @@
 #include "gpak_internal.h"
 
 #define PB 128
-#define PLD 132   // LDS leading dimension of the 128x128 block
-#define DLD 17    // leading dimension of the 16x16 inverse blocks
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -25,9 +23,21 @@ __device__ __forceinline__ double gpak_rdlane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
+// LDS image of the 128x128 block: only the 36 lower 16x16 tiles, each column-major with
+// leading dimension 16 (tile (rt,ct), ct<=rt, at slot rt(rt+1)/2+ct).  73,728 B -- small
+// enough to sit on a CU beside one resident trailing-update workgroup (72 KiB), which is what
+// lets the look-ahead panel actually start while the bulk update runs (a 150 KiB kernel is
+// starved until the whole GEMM grid has drained).  A 16-double tile column is 32 banks wide,
+// so an MFMA fragment read (16 rows x 4 k) is conflict-free.
+__device__ __forceinline__ int gpak_tix(int rt, int ct, int i, int k) {
+  return ((rt * (rt + 1) / 2 + ct) << 8) + (k << 4) + i;
+}
+
 // One workgroup (4 waves) factors the 128x128 block held in LDS, 16 columns at a time:
 //   wave 0   : 16x16 diagonal block in registers (one row per lane, pivots broadcast with
-//              v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps) and its 16x16 inverse
+//              v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps) and its 16x16 inverse,
+//              which is parked in the unused strictly-upper half of the same tile
+//              (transposed; its diagonal goes to dd[])
 //   all waves: panel  P := P * inv(D)^T  and trailing update  C -= P P^T  on
 //              v_mfma_f64_16x16x4_f64 with operands read from LDS
 // then the 128x128 inverse by block forward substitution, one block column per wave pass:
@@ -40,32 +50,36 @@ __device__ __forceinline__ double gpak_rdlane(double v, int l) {
 //   info   : atomicMin of the first failing column (1-based)
 __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv,
                                                           int col0, int *info) {
-  __shared__ double S[PB * PLD];
-  __shared__ double Dinv[8][16 * DLD];
+  __shared__ double T[36 * 256];
+  __shared__ double dd[8][16];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   double *invT = inv + PB * PB;
 
+  // inverse of diagonal block r, element (j,k)
+  auto dinv = [&](int r, int j, int k) -> double {
+    return j > k ? T[gpak_tix(r, r, k, j)] : (j == k ? dd[r][j] : 0.0);
+  };
+
   for (int e = t; e < PB * PB; e += 256) {
-    int r = e & (PB - 1), c = e >> 7;
-    S[r + c * PLD] = A[r + (size_t)c * ld];
+    const int r = e & (PB - 1), c = e >> 7;
+    if ((r >> 4) >= (c >> 4)) T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)] = A[r + (size_t)c * ld];
     // strictly-upper 16x16 tiles of both inverse images are zero (the GEMMs read them)
-    if ((r >> 4) < (c >> 4)) { inv[r + c * PB] = 0.0; invT[c + r * PB] = 0.0; }
+    else { inv[r + c * PB] = 0.0; invT[c + r * PB] = 0.0; }
   }
   __syncthreads();
 
   for (int kb = 0; kb < 8; kb++) {
-    const int c0 = 16 * kb;
     if (w == 0) {
       // ---- (a) diagonal block: row l15 of the block per lane (lanes 16..63 mirror 0..15)
       double a[16], rinv[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) a[k] = S[(c0 + k) * PLD + c0 + l15];
+      for (int k = 0; k < 16; k++) a[k] = T[gpak_tix(kb, kb, l15, k)];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         double d = gpak_rdlane(a[j], j);
         if (!(d > 0.0)) {
-          if (lane == 0) atomicMin(info, col0 + c0 + j + 1);
+          if (lane == 0) atomicMin(info, col0 + 16 * kb + j + 1);
           d = 1.0;
         }
         double r = __builtin_amdgcn_rsq(d);
@@ -85,10 +99,6 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
           a[k] = fma(-a[j], lk, a[k]);
         }
       }
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) S[(c0 + k) * PLD + c0 + l15] = (k <= l15) ? a[k] : 0.0;
-      }
       // inverse of the 16x16 block: lane c solves L x = e_c
       double x[16];
 #pragma unroll
@@ -100,23 +110,29 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
       }
       if (lane < 16) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) Dinv[kb][l15 * DLD + i] = x[i];   // X[i][c=l15]
+        for (int k = 0; k < 16; k++) {
+          // lower part (k <= row): L ;  upper part (k > row = c): inv(D)(k, c) stored transposed
+          T[gpak_tix(kb, kb, l15, k)] = (k <= l15) ? a[k] : x[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          if (i == l15) dd[kb][i] = x[i];
       }
     }
     __syncthreads();
     const int nt = 7 - kb;  // 16-row tiles below the diagonal block
     // ---- (b) panel tiles: P := P * inv(D)^T  (a tile depends only on itself: no barrier inside)
     for (int tt = w; tt < nt; tt += 4) {
-      const int r0 = c0 + 16 + 16 * tt;
+      const int rt = kb + 1 + tt;
       d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        double pa = S[(c0 + 4 * s + l4) * PLD + r0 + l15];
-        double xb = Dinv[kb][(4 * s + l4) * DLD + l15];
+        double pa = T[gpak_tix(rt, kb, l15, 4 * s + l4)];
+        double xb = dinv(kb, l15, 4 * s + l4);  // B[k][j] = inv(D)[j][k]
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, xb, acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) S[(c0 + l15) * PLD + r0 + l4 + 4 * r] = acc[r];
+      for (int r = 0; r < 4; r++) T[gpak_tix(rt, kb, l4 + 4 * r, l15)] = acc[r];
     }
     __syncthreads();
     // ---- (c) trailing update of the lower tiles: C(ti,tj) -= P_ti * P_tj^T
@@ -124,26 +140,26 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
     for (int q = w; q < ntile; q += 4) {
       int ti = 0, rem = q;
       while (rem > ti) { rem -= ti + 1; ti++; }  // q -> (ti, tj=rem), tj <= ti
-      const int ri = c0 + 16 + 16 * ti, rj = c0 + 16 + 16 * rem;
+      const int rti = kb + 1 + ti, rtj = kb + 1 + rem;
       d4 acc;
 #pragma unroll
-      for (int r = 0; r < 4; r++) acc[r] = S[(rj + l15) * PLD + ri + l4 + 4 * r];
+      for (int r = 0; r < 4; r++) acc[r] = T[gpak_tix(rti, rtj, l4 + 4 * r, l15)];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        double pa = -S[(c0 + 4 * s + l4) * PLD + ri + l15];
-        double pb = S[(c0 + 4 * s + l4) * PLD + rj + l15];
+        double pa = -T[gpak_tix(rti, kb, l15, 4 * s + l4)];
+        double pb = T[gpak_tix(rtj, kb, l15, 4 * s + l4)];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) S[(rj + l15) * PLD + ri + l4 + 4 * r] = acc[r];
+      for (int r = 0; r < 4; r++) T[gpak_tix(rti, rtj, l4 + 4 * r, l15)] = acc[r];
     }
     __syncthreads();
   }
 
   // L out (upper part of the block zeroed so the stored matrix is cleanly lower)
   for (int e = t; e < PB * PB; e += 256) {
-    int r = e & (PB - 1), c = e >> 7;
-    A[r + (size_t)c * ld] = r >= c ? S[r + c * PLD] : 0.0;
+    const int r = e & (PB - 1), c = e >> 7;
+    A[r + (size_t)c * ld] = r >= c ? T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)] : 0.0;
   }
 
   // 128x128 inverse, block column c per wave pass: X_cc = inv(D_c),
@@ -153,13 +169,12 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
     const int c = pass ? 7 - w : w;
     d4 Xt[8];
 #pragma unroll
-    for (int s = 0; s < 4; s++) Xt[0][s] = Dinv[c][l15 * DLD + l4 + 4 * s];
+    for (int s = 0; s < 4; s++) Xt[0][s] = dinv(c, l4 + 4 * s, l15);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       const int row = 16 * c + l4 + 4 * s, col = 16 * c + l15;
-      const double v = row >= col ? Xt[0][s] : 0.0;
-      inv[row + col * PB] = v;
-      invT[col + row * PB] = v;
+      inv[row + col * PB] = Xt[0][s];
+      invT[col + row * PB] = Xt[0][s];
     }
 #pragma unroll
     for (int rr = 1; rr < 8; rr++) {
@@ -168,17 +183,16 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
         d4 G = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int m = 0; m < rr; m++) {
-          const int k0 = 16 * (c + m);
 #pragma unroll
           for (int s = 0; s < 4; s++) {
-            double la = S[(k0 + 4 * s + l4) * PLD + 16 * r + l15];
+            double la = T[gpak_tix(r, c + m, l15, 4 * s + l4)];
             G = __builtin_amdgcn_mfma_f64_16x16x4f64(la, Xt[m][s], G, 0, 0, 0);
           }
         }
         d4 Xn = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-          double da = -Dinv[r][(4 * s + l4) * DLD + l15];
+          double da = -dinv(r, l15, 4 * s + l4);
           Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(da, G[s], Xn, 0, 0, 0);
         }
         Xt[rr] = Xn;
@@ -197,60 +211,107 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
   hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(256), 0, st, A, ld, inv, col0, info);
 }
 
-int gpak_potrf_blocked(gpak_ctx *ctx) {
+// Panel factorisation of one outer block column [J, J+W): all rows below it.
+static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W) {
   const int Np = ctx->Np;
   const long ld = ctx->ld;
   double *M = ctx->dM;
-  hipStream_t st = ctx->stream;
+  for (int j = J; j < J + W; j += PB) {
+    double *inv = ctx->dInv + (size_t)(j / PB) * 2 * PB * PB;
+    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo);
+    const int mt = (Np - j - PB) / PB;
+    if (mt > 0) {
+      double *P = M + (j + PB) + (size_t)j * ld;
+      gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, P, ld, inv, PB, 0.0, P, ld, 0, 0, false, false);
+      const int nct = (J + W - (j + PB)) / PB;
+      if (nct > 0)
+        gpak_launch_gemm_nt(st, mt, nct, PB, -1.0, P, ld, P, ld, 1.0, M + (j + PB) + (size_t)(j + PB) * ld,
+                            ld, 0, 0, true, false);
+    }
+  }
+}
+
+// Update of the columns [c0, c1) (and all rows >= c0) with the factored panel [J, J+W).
+static void update_cols(gpak_ctx *ctx, hipStream_t st, int J, int W, int c0, int c1, bool trailing) {
+  const long ld = ctx->ld;
+  double *M = ctx->dM;
+  const int mt = (ctx->Np - c0) / PB, nt = (c1 - c0) / PB;
+  if (mt <= 0 || nt <= 0) return;
+  const double *P = M + c0 + (size_t)J * ld;
+  gpak_launch_gemm_nt(st, mt, nt, W, -1.0, P, ld, P, ld, 1.0, M + c0 + (size_t)c0 * ld, ld, 0, 0, true,
+                      trailing);
+}
+
+// Right-looking blocked factorisation with one panel of look-ahead:
+//   panel stream (high priority):  F(0) | T(0,1) F(1) | T(1,2) F(2) | ...
+//   update stream (ctx->stream)  :        T(0,2..)    | T(1,3..)    | ...
+// F(b) = factor_panel of outer block b, T(b,c) = update of block column c with panel b.
+// T(b,b+1) waits for the previous bulk update (which touched column b+1); the bulk update
+// T(b,b+2..) waits for F(b).  While the MFMA-bound bulk update of step b runs, the latency-
+// bound panel work of step b+1 proceeds beside it.
+int gpak_potrf_blocked(gpak_ctx *ctx) {
+  const int Np = ctx->Np;
+  // without look-ahead everything is queued on the one main stream, in the classical order
+  hipStream_t su = ctx->stream, sp = ctx->lookahead ? ctx->stream_hi : ctx->stream;
   int NB = ctx->nb_outer;
   if (NB < PB) NB = PB;
   NB = NB / PB * PB;
+  const int nJ = (Np + NB - 1) / NB;
   const int init = 0x7fffffff;
-  GPAK_HIP(hipMemcpyAsync(ctx->dInfo, &init, sizeof(int), hipMemcpyHostToDevice, st));
+  GPAK_HIP(hipMemcpyAsync(ctx->dInfo, &init, sizeof(int), hipMemcpyHostToDevice, su));
+
+  while ((int)ctx->ev_sync.size() < 2 * nJ + 2) {
+    hipEvent_t e;
+    GPAK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->ev_sync.push_back(e);
+  }
+  hipEvent_t *EF = ctx->ev_sync.data(), *EU = ctx->ev_sync.data() + nJ;
+  hipEvent_t Estart = ctx->ev_sync[2 * nJ], Eend = ctx->ev_sync[2 * nJ + 1];
+  // the panel stream starts after everything queued so far on the main stream (the fill)
+  GPAK_HIP(hipEventRecord(Estart, su));
+  GPAK_HIP(hipStreamWaitEvent(sp, Estart, 0));
 
   size_t ev_used = 0;
   double tflops = 0.0;
   int tl = 0;
-  for (int J = 0; J < Np; J += NB) {
+  for (int b = 0; b < nJ; b++) {
+    const int J = b * NB;
     const int W = (Np - J) < NB ? (Np - J) : NB;
-    for (int j = J; j < J + W; j += PB) {
-      double *inv = ctx->dInv + (size_t)(j / PB) * 2 * PB * PB;
-      gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo);
-      const int mt = (Np - j - PB) / PB;
-      if (mt > 0) {
-        double *P = M + (j + PB) + (size_t)j * ld;
-        gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, P, ld, inv, PB, 0.0, P, ld, 0, 0, false, false);
-        const int nct = (J + W - (j + PB)) / PB;
-        if (nct > 0)
-          gpak_launch_gemm_nt(st, mt, nct, PB, -1.0, P, ld, P, ld, 1.0,
-                              M + (j + PB) + (size_t)(j + PB) * ld, ld, 0, 0, true, false);
-      }
-    }
-    const int mt = (Np - J - W) / PB;
-    if (mt > 0) {
-      double *P = M + (J + W) + (size_t)J * ld;
-      double *Cc = M + (J + W) + (size_t)(J + W) * ld;
+    factor_panel(ctx, sp, J, W);
+    GPAK_HIP(hipEventRecord(EF[b], sp));
+    const int J1 = J + W;
+    if (J1 >= Np) break;
+    const int W1 = (Np - J1) < NB ? (Np - J1) : NB;
+    const int J2 = J1 + W1;
+    // next panel's columns first, on the panel stream (after the previous bulk update)
+    if (b > 0) GPAK_HIP(hipStreamWaitEvent(sp, EU[b - 1], 0));
+    update_cols(ctx, sp, J, W, J1, J2, false);
+    if (J2 < Np) {
+      GPAK_HIP(hipStreamWaitEvent(su, EF[b], 0));
       if (ctx->profile) {
         while (ctx->ev_pool.size() < ev_used + 2) {
           hipEvent_t e;
           GPAK_HIP(hipEventCreate(&e));
           ctx->ev_pool.push_back(e);
         }
-        GPAK_HIP(hipEventRecord(ctx->ev_pool[ev_used], st));
+        GPAK_HIP(hipEventRecord(ctx->ev_pool[ev_used], su));
       }
-      gpak_launch_gemm_nt(st, mt, mt, W, -1.0, P, ld, P, ld, 1.0, Cc, ld, 0, 0, true, true);
+      update_cols(ctx, su, J, W, J2, Np, true);
       if (ctx->profile) {
-        GPAK_HIP(hipEventRecord(ctx->ev_pool[ev_used + 1], st));
+        GPAK_HIP(hipEventRecord(ctx->ev_pool[ev_used + 1], su));
         ev_used += 2;
       }
-      // algorithmic flops of this launch: lower tiles only, 2*128*128*W each
-      tflops += (double)mt * (mt + 1) / 2.0 * 2.0 * PB * PB * W;
+      const double mt = (Np - J2) / PB;
+      tflops += mt * (mt + 1) / 2.0 * 2.0 * PB * PB * W;  // lower tiles only
       tl++;
     }
+    GPAK_HIP(hipEventRecord(EU[b], su));
   }
   int info = 0;
-  GPAK_HIP(hipMemcpyAsync(&info, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, st));
-  GPAK_HIP(hipStreamSynchronize(st));
+  GPAK_HIP(hipEventRecord(Eend, sp));
+  GPAK_HIP(hipStreamWaitEvent(su, Eend, 0));
+  GPAK_HIP(hipMemcpyAsync(&info, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, su));
+  GPAK_HIP(hipStreamSynchronize(su));
   ctx->times.trailing_flops = tflops;
   ctx->times.trailing_launches = tl;
   ctx->times.trailing_ms = 0.0;

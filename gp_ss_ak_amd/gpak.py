@@ -15,7 +15,7 @@ OK, ENOTPD, EINVAL, ESTATE, ENOMEM, ENOTIMPL, EHIP = 0, 1, 2, 3, 4, 5, -1
 F64, F32 = 0, 1
 DIST_EXPANSION, DIST_DIRECT = 0, 1
 COMPAT_VARCLAMP, COMPAT_SN2SKIP = 1, 2
-OPT_MEMOISE, OPT_NB_OUTER, OPT_PROFILE = 1, 2, 3
+OPT_MEMOISE, OPT_NB_OUTER, OPT_PROFILE, OPT_LOOKAHEAD = 1, 2, 3, 4
 
 _dp = C.POINTER(C.c_double)
 

@@ -75,6 +75,7 @@ int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2
 #define GPAK_OPT_MEMOISE   1  /* value-based dirty tracking instead of always-invalidate   */
 #define GPAK_OPT_NB_OUTER  2  /* outer Cholesky block width (multiple of 128)              */
 #define GPAK_OPT_PROFILE   3  /* 1: bracket each trailing-update launch with hip events    */
+#define GPAK_OPT_LOOKAHEAD 4  /* 1 (default): factor the next panel beside the bulk update */
 int gpak_set_option(gpak_ctx *ctx, int option, long value);
 
 /* ---- hot path --------------------------------------------------------------------------- */
