@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--calibrate", action="store_true", default=True)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("GPAK_FORCE_DIST"):
         from gp_ss_ak_amd import multigpu
         out = multigpu.bench(args)
         if out is not None:

@@ -35,7 +35,7 @@ int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap) {
 }
 
 // sigInv = Rot * lambda * Rot^T, Kernel.cpp:1399-1425 (host, 3x3)
-static void build_siginv(const double *e, double *A) {
+void gpak_build_siginv(const double *e, double *A) {
   const double alpha = e[0], beta = e[2], teta = e[4];
   const double lam[3] = {e[1], e[3], e[5]};
   double R[9];
@@ -205,7 +205,7 @@ int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2
   memcpy(ctx->expans, expans, sizeof(double) * 8);
   ctx->bias = bias; ctx->sn2 = sn2; ctx->dist_mode = dist_mode;
   ctx->have_params = true;
-  build_siginv(expans, ctx->kp.A);
+  gpak_build_siginv(expans, ctx->kp.A);
   ctx->kp.var2 = expans[6] * expans[6];
   ctx->kp.bias = bias;
   ctx->kp.mode = dist_mode;

@@ -1,0 +1,110 @@
+// dev_api.hip -- device-pointer level C-ABI (include/gpak_dev.h): what one rank of the
+// block-column-cyclic multi-GPU factorisation runs on the block columns it owns.
+#include <cmath>
+
+#include "../../include/gpak_dev.h"
+#include "gpak_internal.h"
+
+void gpak_build_siginv(const double *e, double *A);
+
+static DevPoints as_points(const double *u, int cap, int n, int off = 0) {
+  DevPoints p;
+  double *b = const_cast<double *>(u);
+  p.u0 = b + off; p.u1 = b + cap + off; p.u2 = b + 2 * (size_t)cap + off; p.s = b + 3 * (size_t)cap + off;
+  p.n = n - off;
+  p.cap = cap - off;
+  return p;
+}
+static KernParams make_kp(const double *expans, double bias, int mode, const double *mu) {
+  KernParams kp;
+  gpak_build_siginv(expans, kp.A);
+  for (int k = 0; k < 3; k++) kp.mu[k] = mu ? mu[k] : 0.0;
+  kp.var2 = expans[6] * expans[6];
+  kp.bias = bias;
+  kp.mode = mode;
+  return kp;
+}
+static int status() { return hipGetLastError() == hipSuccess ? GPAK_OK : GPAK_EHIP; }
+
+extern "C" {
+
+int gpak_dev_transform(void *stream, const double *x, int xs, int n, int cap, const double *expans,
+                       const double *mu, double *u) {
+  KernParams kp = make_kp(expans, 0.0, GPAK_DIST_DIRECT, mu);
+  DevPoints p = as_points(u, cap, n);
+  gpak_launch_transform((hipStream_t)stream, x, xs, n, kp, p);
+  return status();
+}
+
+int gpak_dev_fill_b(void *stream, const double *u, int cap, int n, int Np, int J, int W, const double *expans,
+                    double bias, double sn2, int dist_mode, double *blk, long ld) {
+  KernParams kp = make_kp(expans, bias, dist_mode, nullptr);
+  DevPoints P = as_points(u, cap, n), Q = as_points(u, cap, n, J);
+  gpak_launch_fill((hipStream_t)stream, P, Q, Np, W, kp, 1.0 / sn2, 1.0, 1.0, 1, blk, ld, nullptr, J);
+  return status();
+}
+
+int gpak_dev_factor_panel(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info) {
+  // virtual bases: global (row, column) addressing that only ever touches columns [J, J+W)
+  double *Mv = blk - (size_t)J * ld;
+  double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
+  gpak_factor_panel((hipStream_t)stream, Mv, ld, Np, J, W, invv, info);
+  return status();
+}
+
+int gpak_dev_update_block(void *stream, const double *panel, long ldp, int prow0, int W, double *blk, long ld,
+                          int Np, int Jc, int Wc) {
+  const int mt = (Np - Jc) / GPAK_TILE, nt = Wc / GPAK_TILE;
+  const double *P = panel + (Jc - prow0);
+  // C[rows >= Jc, cols of c] -= P[rows >= Jc] * P[rows of c]^T, lower tiles only
+  gpak_launch_gemm_nt((hipStream_t)stream, mt, nt, W, -1.0, P, ldp, P, ldp, 1.0, blk + Jc, ld, 0, 0, true, true);
+  return status();
+}
+
+int gpak_dev_trsv_fwd_block(void *stream, const double *blk, long ld, int Np, int J, int W, const double *inv,
+                            double *x, double *out) {
+  const double *Lv = blk - (size_t)J * ld;
+  const double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
+  gpak_launch_trsv_fwd_block((hipStream_t)stream, Np, J, W, Lv, ld, invv, x, out);
+  return status();
+}
+
+int gpak_dev_coldot(void *stream, const double *blk, long ld, int Np, int J, int W, const double *x, double *s) {
+  const double *Lv = blk - (size_t)J * ld;
+  gpak_launch_coldot((hipStream_t)stream, Np, J + W, J, W, Lv, ld, x, s);
+  return status();
+}
+
+int gpak_dev_trsv_bwd_block(void *stream, const double *blk, long ld, int J, int W, const double *inv, double *x,
+                            double *out) {
+  const double *Lv = blk - (size_t)J * ld;
+  const double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
+  gpak_launch_trsv_bwd_block((hipStream_t)stream, J, W, Lv, ld, invv, x, out);
+  return status();
+}
+
+int gpak_dev_logdiag_block(void *stream, const double *blk, long ld, int J, int W, int N, double *out) {
+  const double *Lv = blk - (size_t)J * ld;
+  gpak_launch_logdiag_block((hipStream_t)stream, J, W, N, Lv, ld, out);
+  return status();
+}
+
+int gpak_dev_kmatvec(void *stream, const double *u, int cap, int n, int i0, int i1, const double *w,
+                     const double *expans, double bias, int dist_mode, double *scratch, double *out) {
+  KernParams kp = make_kp(expans, bias, dist_mode, nullptr);
+  DevPoints Q = as_points(u, cap, n);
+  DevPoints P = as_points(u, cap, i1, i0);  // source points [i0, i1)
+  P.cap = Q.cap;
+  int splits = gpak_kmatvec_splits(P.n, Q.n);
+  gpak_launch_kmatvec((hipStream_t)stream, P, w + i0, Q, kp, scratch, splits, out);
+  return status();
+}
+
+int gpak_dev_nlz_terms(void *stream, int N, const double *y, const double *f, const double *alpha, double sn2,
+                       double *out) {
+  // the launcher writes red[1], red[2]; shift so that they land in out[0], out[1]
+  gpak_launch_nlz_terms((hipStream_t)stream, N, y, f, alpha, sn2, out - 1);
+  return status();
+}
+
+}  // extern "C"

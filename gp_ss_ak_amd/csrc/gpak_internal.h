@@ -99,7 +99,7 @@ void gpak_launch_transform(hipStream_t st, const double *x, int xs, int n, const
 // the valid counts get delta_ij. lower_only skips tiles strictly above the diagonal.
 void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, int rows_p, int cols_p,
                       const KernParams &kp, double scale, double diag, double pad_diag, int lower_only,
-                      double *C, long ld, double *D2out);
+                      double *C, long ld, double *D2out, int col_off = 0);
 // out_j = sum_i w_i K(P_i, Q_j), j < Q.n   (fused Gram-matvec; K never stored).
 // scratch holds splits * Q.cap doubles.
 int gpak_kmatvec_splits(int nP, int nQ);
@@ -121,6 +121,7 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
 // Factor the 128x128 block at A (ld) in place (lower), write its inverse to inv (128x128, ld 128).
 void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info);
 int gpak_potrf_blocked(gpak_ctx *ctx);
+void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info);
 
 // ---- solve.hip --------------------------------------------------------------------------
 // x := L^-1 x ; x := L^-T x  (x has Np entries) using the inverted diagonal blocks.
@@ -129,6 +130,13 @@ void gpak_launch_trsv_fwd(hipStream_t st, int Np, const double *L, long ld, cons
                           double *out);
 void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,
                           double *out);
+void gpak_launch_trsv_fwd_block(hipStream_t st, int Np, int J, int W, const double *L, long ld,
+                                const double *inv, double *x, double *out);
+void gpak_launch_trsv_bwd_block(hipStream_t st, int J, int W, const double *L, long ld, const double *inv,
+                                double *x, double *out);
+void gpak_launch_coldot(hipStream_t st, int Np, int i0, int J, int W, const double *L, long ld, const double *x,
+                        double *s);
+void gpak_launch_logdiag_block(hipStream_t st, int J, int W, int N, const double *L, long ld, double *out);
 // red[0] = sum log L_ii (i < N)
 void gpak_launch_logdet(hipStream_t st, int N, const double *L, long ld, double *red);
 // red[1] = sum alpha_i * 0.5 f_i ; red[2] = sum lp_i   (GP_Utils.cpp:810, 1159)

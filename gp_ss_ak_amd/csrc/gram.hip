@@ -60,9 +60,10 @@ __global__ __launch_bounds__(256) void gpak_fill_f64(
     const double *__restrict__ ps, int nP, const double *__restrict__ qu0, const double *__restrict__ qu1,
     const double *__restrict__ qu2, const double *__restrict__ qs, int nQ, double var2, double bias,
     int mode, double scale, double diag, double pad_diag, int lower_only, double *__restrict__ C, long ld,
-    double *__restrict__ D2out) {
+    double *__restrict__ D2out, int col_off) {
   const int row0 = blockIdx.x * FILL_ROWS, col0 = blockIdx.y * FILL_COLS;
-  if (lower_only && row0 + FILL_ROWS <= col0) return;
+  // col_off: global index of the first column when only a block column of the matrix is filled
+  if (lower_only && row0 + FILL_ROWS <= col0 + col_off) return;
   __shared__ double q[4][FILL_COLS];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t < FILL_COLS) {
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(256) void gpak_fill_f64(
     const bool cj = j < nQ;
     if (!(cj && r < nP)) { k0 = 0.0; d0 = 0.0; }
     if (!(cj && r + 1 < nP)) { k1 = 0.0; d1 = 0.0; }
-    if (r == j) k0 += (cj && r < nP) ? diag : pad_diag;
-    if (r + 1 == j) k1 += (cj && r + 1 < nP) ? diag : pad_diag;
+    if (r == j + col_off) k0 += (cj && r < nP) ? diag : pad_diag;
+    if (r + 1 == j + col_off) k1 += (cj && r + 1 < nP) ? diag : pad_diag;
     *reinterpret_cast<double2 *>(C + r + (size_t)j * ld) = make_double2(k0, k1);
     if (D2out) *reinterpret_cast<double2 *>(D2out + r + (size_t)j * ld) = make_double2(d0, d1);
   }
@@ -99,10 +100,10 @@ __global__ __launch_bounds__(256) void gpak_fill_f64(
 
 void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, int rows_p, int cols_p,
                       const KernParams &kp, double scale, double diag, double pad_diag, int lower_only,
-                      double *C, long ld, double *D2out) {
+                      double *C, long ld, double *D2out, int col_off) {
   dim3 grid(rows_p / FILL_ROWS, cols_p / FILL_COLS);
   hipLaunchKernelGGL(gpak_fill_f64, grid, dim3(256), 0, st, P.u0, P.u1, P.u2, P.s, P.n, Q.u0, Q.u1, Q.u2,
-                     Q.s, Q.n, kp.var2, kp.bias, kp.mode, scale, diag, pad_diag, lower_only, C, ld, D2out);
+                     Q.s, Q.n, kp.var2, kp.bias, kp.mode, scale, diag, pad_diag, lower_only, C, ld, D2out, col_off);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -212,13 +212,12 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
 }
 
 // Panel factorisation of one outer block column [J, J+W): all rows below it.
-static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W) {
-  const int Np = ctx->Np;
-  const long ld = ctx->ld;
-  double *M = ctx->dM;
+// M is addressed with GLOBAL (row, column) indices; only columns [J, J+W) are touched, so a
+// rank that stores just this block column passes a virtual base (see dev_api.hip).
+void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info) {
   for (int j = J; j < J + W; j += PB) {
-    double *inv = ctx->dInv + (size_t)(j / PB) * 2 * PB * PB;
-    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo);
+    double *inv = inv_base + (size_t)(j / PB) * 2 * PB * PB;
+    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info);
     const int mt = (Np - j - PB) / PB;
     if (mt > 0) {
       double *P = M + (j + PB) + (size_t)j * ld;
@@ -229,6 +228,9 @@ static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W) {
                             ld, 0, 0, true, false);
     }
   }
+}
+static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W) {
+  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo);
 }
 
 // Update of the columns [c0, c1) (and all rows >= c0) with the factored panel [J, J+W).

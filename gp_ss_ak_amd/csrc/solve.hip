@@ -13,6 +13,8 @@
 
 #define SB 128
 
+__device__ __forceinline__ double gpak_block_sum(double v, double *sh);
+
 // forward: out_j = inv_j * x_j ;  x[r] -= L[r, jblock] * out_j  for r > jblock
 __global__ __launch_bounds__(256) void gpak_trsv_fwd_f64(int Np, int jb, const double *__restrict__ L,
                                                           long ld, const double *__restrict__ inv,
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(256) void gpak_trsv_fwd_f64(int Np, int jb, const d
 // backward: out_j = inv_j^T * x_j ;  x[c] -= L[jblock, c]^T * out_j  for c < jblock
 __global__ __launch_bounds__(256) void gpak_trsv_bwd_f64(int jb, const double *__restrict__ L, long ld,
                                                           const double *__restrict__ inv, double *x,
-                                                          double *__restrict__ out, int cols_per_wg) {
+                                                          double *__restrict__ out, int cols_per_wg,
+                                                          int c_begin) {
   __shared__ double xs[SB], zs[SB], part[256];
   const int t = threadIdx.x;
   const int j0 = jb * SB;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void gpak_trsv_bwd_f64(int jb, const double *_
   __syncthreads();
   const int lane = t & 63, w = t >> 6;
   const double z0 = zs[2 * lane], z1 = zs[2 * lane + 1];
-  const int cbeg = blockIdx.x * cols_per_wg;
+  const int cbeg = c_begin + blockIdx.x * cols_per_wg;
   const int cend = min(j0, cbeg + cols_per_wg);
   for (int c = cbeg + w; c < cend; c += 4) {
     const double2 l = *reinterpret_cast<const double2 *>(L + j0 + 2 * lane + (size_t)c * ld);
@@ -102,8 +105,67 @@ void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, cons
     int cols = jb * SB;
     int cpw = 32;
     int grid = cols > 0 ? (cols + cpw - 1) / cpw : 1;
-    hipLaunchKernelGGL(gpak_trsv_bwd_f64, dim3(grid), dim3(256), 0, st, jb, L, ld, inv, x, out, cpw);
+    hipLaunchKernelGGL(gpak_trsv_bwd_f64, dim3(grid), dim3(256), 0, st, jb, L, ld, inv, x, out, cpw, 0);
   }
+}
+
+// ---- block-column pieces for a factor that is distributed by block columns ---------------
+// forward: the four (W/128) steps of block column [J, J+W); x[r] is updated for ALL r below
+void gpak_launch_trsv_fwd_block(hipStream_t st, int Np, int J, int W, const double *L, long ld,
+                                const double *inv, double *x, double *out) {
+  for (int jb = J / SB; jb < (J + W) / SB; jb++) {
+    int rest = Np - (jb + 1) * SB;
+    int grid = rest > 0 ? (rest + 255) / 256 : 1;
+    hipLaunchKernelGGL(gpak_trsv_fwd_f64, dim3(grid), dim3(256), 0, st, Np, jb, L, ld, inv, x, out);
+  }
+}
+// backward inside the diagonal block of block column [J, J+W): only columns >= J are updated
+void gpak_launch_trsv_bwd_block(hipStream_t st, int J, int W, const double *L, long ld, const double *inv,
+                                double *x, double *out) {
+  for (int jb = (J + W) / SB - 1; jb >= J / SB; jb--) {
+    int cols = jb * SB - J;
+    int cpw = 32;
+    int grid = cols > 0 ? (cols + cpw - 1) / cpw : 1;
+    hipLaunchKernelGGL(gpak_trsv_bwd_f64, dim3(grid), dim3(256), 0, st, jb, L, ld, inv, x, out, cpw, J);
+  }
+}
+
+// s[c - J] = sum_{i >= i0} L[i, c] * x[i]  for the W columns c of a block column (one wave per column)
+__global__ __launch_bounds__(256) void gpak_coldot_f64(int Np, int i0, int J, int W, const double *__restrict__ L,
+                                                        long ld, const double *__restrict__ x,
+                                                        double *__restrict__ s) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = J + blockIdx.x * 4 + w;
+  if (c >= J + W) return;
+  const double *Lc = L + (size_t)c * ld;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = i0 + 2 * lane; i < Np; i += 128) {
+    const double2 l = *reinterpret_cast<const double2 *>(Lc + i);
+    const double2 v = *reinterpret_cast<const double2 *>(x + i);
+    a0 = fma(l.x, v.x, a0);
+    a1 = fma(l.y, v.y, a1);
+  }
+  double a = a0 + a1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  if (lane == 0) s[c - J] = a;
+}
+void gpak_launch_coldot(hipStream_t st, int Np, int i0, int J, int W, const double *L, long ld, const double *x,
+                        double *s) {
+  hipLaunchKernelGGL(gpak_coldot_f64, dim3((W + 3) / 4), dim3(256), 0, st, Np, i0, J, W, L, ld, x, s);
+}
+
+// out[0] = sum_{c in [J, min(J+W, N))} log L[c, c]
+__global__ __launch_bounds__(256) void gpak_logdiag_block_f64(int J, int W, int N, const double *__restrict__ L,
+                                                               long ld, double *out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int c = J + threadIdx.x; c < J + W && c < N; c += 256) s += log(L[c + (size_t)c * ld]);
+  s = gpak_block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s;
+}
+void gpak_launch_logdiag_block(hipStream_t st, int J, int W, int N, const double *L, long ld, double *out) {
+  hipLaunchKernelGGL(gpak_logdiag_block_f64, dim3(1), dim3(256), 0, st, J, W, N, L, ld, out);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,372 @@
+"""Multi-GPU hot path: block-column-cyclic Cholesky / solves / nlZ, one process per GPU.
+
+The reference is a single process; this is the build's own distribution of
+GP_utils::ldB2_exact / solve_chol / logLikelihood (GP_Utils.cpp:841-845, 872-915, 1138-1162):
+
+  * outer block column b (width nb) of B = I + K/sn2 lives on rank b % P, nowhere else
+    (N=65536: 32 GiB / P per GPU);
+  * fill: every rank fills its own block columns from the replicated coordinates -- no
+    communication;
+  * factor: the owner factors block column b and BROADCASTS the panel below its diagonal block
+    (the only bulk collective: RCCL broadcast over xGMI); every rank then updates the block
+    columns it owns.  One panel of look-ahead: the owner of b+1 updates and factors its column
+    first and its broadcast is in flight while all ranks run the bulk update with panel b;
+  * solves: forward substitution needs one nb-entry all-reduce per block column, backward one
+    nb-entry broadcast; f = K*alpha is an N-entry all-reduce of per-rank partial sums; log-det
+    a scalar all-reduce.
+
+torch is plumbing here: device memory (tensors), streams and torch.distributed ("nccl" = RCCL on
+ROCm; "gloo" on CPU for the tests).  All arithmetic goes through the engine: `HipEngine` calls
+the gpak_dev_* C-ABI of libgpak_hip.so (include/gpak_dev.h).  The schedule below is engine- and
+backend-agnostic so that the world_size-2 gloo tests exercise exactly this code.
+"""
+import ctypes as C
+import math
+import os
+import time
+
+import numpy as np
+
+TILE = 128
+INT_MAX = 0x7FFFFFFF
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class HipEngine:
+    """gpak_dev_* over torch CUDA(=HIP) tensors.  Fails loudly if the library is missing."""
+
+    def __init__(self, device_index):
+        torch = _torch()
+        from . import _lib
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs a GPU (there is no CPU fallback)")
+        torch.cuda.set_device(device_index)
+        self.device = torch.device("cuda", device_index)
+        self.lib = _lib.load()
+        for name in ("gpak_dev_transform", "gpak_dev_fill_b", "gpak_dev_factor_panel", "gpak_dev_update_block",
+                     "gpak_dev_trsv_fwd_block", "gpak_dev_coldot", "gpak_dev_trsv_bwd_block",
+                     "gpak_dev_logdiag_block", "gpak_dev_kmatvec", "gpak_dev_nlz_terms"):
+            if not hasattr(self.lib, name):
+                raise RuntimeError(f"libgpak_hip.so lacks {name}")
+            getattr(self.lib, name).restype = C.c_int
+        self._host_e = None
+
+    # -- memory ------------------------------------------------------------------------------
+    def empty(self, n, dtype=None):
+        torch = _torch()
+        return torch.empty(int(n), dtype=dtype or torch.float64, device=self.device)
+
+    def zeros(self, n, dtype=None):
+        torch = _torch()
+        return torch.zeros(int(n), dtype=dtype or torch.float64, device=self.device)
+
+    def from_numpy(self, a):
+        torch = _torch()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def sync(self):
+        _torch().cuda.synchronize()
+
+    def _st(self):
+        return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def _e(self, expans):
+        self._host_e = (C.c_double * 8)(*[float(v) for v in expans])
+        return self._host_e
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with status {rc}")
+
+    # -- tile operations (include/gpak_dev.h) ---------------------------------------------------
+    def transform(self, x_soa, xs, n, cap, expans, mu, u):
+        m = (C.c_double * 3)(*[float(v) for v in mu])
+        self._chk(self.lib.gpak_dev_transform(self._st(), self._p(x_soa), xs, n, cap, self._e(expans), m,
+                                              self._p(u)), "gpak_dev_transform")
+
+    def fill_b(self, u, cap, n, Np, J, W, expans, bias, sn2, mode, blk, ld):
+        self._chk(self.lib.gpak_dev_fill_b(self._st(), self._p(u), cap, n, Np, J, W, self._e(expans),
+                                           C.c_double(bias), C.c_double(sn2), mode, self._p(blk), C.c_long(ld)),
+                  "gpak_dev_fill_b")
+
+    def factor_panel(self, blk, ld, Np, J, W, inv, info):
+        self._chk(self.lib.gpak_dev_factor_panel(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(inv),
+                                                 self._p(info)), "gpak_dev_factor_panel")
+
+    def update_block(self, panel, ldp, prow0, W, blk, ld, Np, Jc, Wc):
+        self._chk(self.lib.gpak_dev_update_block(self._st(), self._p(panel), C.c_long(ldp), prow0, W, self._p(blk),
+                                                 C.c_long(ld), Np, Jc, Wc), "gpak_dev_update_block")
+
+    def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out):
+        self._chk(self.lib.gpak_dev_trsv_fwd_block(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(inv),
+                                                   self._p(x), self._p(out)), "gpak_dev_trsv_fwd_block")
+
+    def coldot(self, blk, ld, Np, J, W, x, s):
+        self._chk(self.lib.gpak_dev_coldot(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(x), self._p(s)),
+                  "gpak_dev_coldot")
+
+    def trsv_bwd_block(self, blk, ld, J, W, inv, x, out):
+        self._chk(self.lib.gpak_dev_trsv_bwd_block(self._st(), self._p(blk), C.c_long(ld), J, W, self._p(inv),
+                                                   self._p(x), self._p(out)), "gpak_dev_trsv_bwd_block")
+
+    def logdiag_block(self, blk, ld, J, W, N, out):
+        self._chk(self.lib.gpak_dev_logdiag_block(self._st(), self._p(blk), C.c_long(ld), J, W, N, self._p(out)),
+                  "gpak_dev_logdiag_block")
+
+    def kmatvec(self, u, cap, n, i0, i1, w, expans, bias, mode, scratch, out):
+        self._chk(self.lib.gpak_dev_kmatvec(self._st(), self._p(u), cap, n, i0, i1, self._p(w), self._e(expans),
+                                            C.c_double(bias), mode, self._p(scratch), self._p(out)),
+                  "gpak_dev_kmatvec")
+
+    def nlz_terms(self, N, y, f, alpha, sn2, out):
+        self._chk(self.lib.gpak_dev_nlz_terms(self._st(), N, self._p(y), self._p(f), self._p(alpha),
+                                              C.c_double(sn2), self._p(out)), "gpak_dev_nlz_terms")
+
+
+class DistGP:
+    """The hot path on P ranks.  Every rank calls the same methods in the same order."""
+
+    def __init__(self, engine, X, y, nb=512, group=None):
+        torch = _torch()
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.eng = engine
+        self.P = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+        self.N = X.shape[0]
+        assert X.shape[1] == 3, "HIP path handles 3-D inputs"
+        self.Np = (self.N + TILE - 1) // TILE * TILE
+        self.ld = self.Np + (32 if self.Np >= 1024 else 0)
+        self.nb = max(TILE, nb // TILE * TILE)
+        self.nJ = (self.Np + self.nb - 1) // self.nb
+        self.cap = self.Np
+        self.owned = [b for b in range(self.nJ) if b % self.P == self.rank]
+        xs = np.zeros((3, self.Np))
+        xs[:, :self.N] = X.T
+        self.x_soa = engine.from_numpy(xs.ravel())
+        yp = np.zeros(self.Np)
+        yp[:self.N] = y
+        self.y = engine.from_numpy(yp)
+        self.xsum = X.sum(axis=0)
+        self.u = engine.empty(4 * self.cap)
+        self.blk = {b: engine.empty(self.ld * self.width(b)) for b in self.owned}
+        self.inv = {b: engine.empty(self.width(b) // TILE * 2 * TILE * TILE) for b in self.owned}
+        self.info = engine.zeros(4, dtype=torch.int32)
+        self.scratch = engine.empty(64 * self.cap)
+        self.small = engine.zeros(8)
+        self.alpha = engine.zeros(self.Np)
+        self.params = None
+        self.bytes_broadcast = 0
+
+    def start(self, b):
+        return b * self.nb
+
+    def width(self, b):
+        return min(self.nb, self.Np - b * self.nb)
+
+    def owner(self, b):
+        return b % self.P
+
+    # GP_utils::set_GP_Pars (GP_Utils.cpp:130-157): parameters are replicated, 10 doubles
+    def set_params(self, expans, bias, sn2, dist_mode=1):
+        self.params = (np.array(expans, dtype=np.float64), float(bias), float(sn2), int(dist_mode))
+
+    def _bcast(self, t, src, async_op=False):
+        if self.P == 1:
+            return None
+        return self.dist.broadcast(t, src=src, group=self.group, async_op=async_op)
+
+    def _allreduce(self, t):
+        if self.P > 1:
+            self.dist.all_reduce(t, group=self.group)
+
+    # ---- fill: HybKerns::computeK + the "(sW sW') % K + I" of ldB2_exact, owned columns only ----
+    def fill(self):
+        e, bias, sn2, mode = self.params
+        n = float(self.N)
+        # pooled mean of X u X (Kernel.cpp:1391-1392)
+        mX1 = n / (2 * n) * self.xsum / n
+        mu = n / (2 * n) * self.xsum / n + mX1
+        self.eng.transform(self.x_soa, self.Np, self.N, self.cap, e, mu, self.u)
+        for b in self.owned:
+            self.eng.fill_b(self.u, self.cap, self.N, self.Np, self.start(b), self.width(b), e, bias, sn2, mode,
+                            self.blk[b], self.ld)
+
+    # ---- factor: right-looking, one panel of look-ahead, panel broadcast is the only bulk collective
+    def _factor_and_pack(self, b):
+        J, W = self.start(b), self.width(b)
+        rows = self.Np - (J + W)
+        if self.rank == self.owner(b):
+            self.eng.factor_panel(self.blk[b], self.ld, self.Np, J, W, self.inv[b], self.info)
+            if rows > 0:
+                return self.blk[b].view(W, self.ld)[:, J + W:self.Np].contiguous().view(-1)
+            return None
+        return self.eng.empty(W * rows) if rows > 0 else None
+
+    def factor(self):
+        """Returns 0, or the first failing column (1-based) like LAPACK dpotrf's info."""
+        torch = _torch()
+        self.info.fill_(INT_MAX)
+        self.bytes_broadcast = 0
+        panel = self._factor_and_pack(0)
+        if panel is not None:
+            self._bcast(panel, self.owner(0))
+            self.bytes_broadcast += panel.numel() * 8
+        for b in range(self.nJ):
+            J, W = self.start(b), self.width(b)
+            rows = self.Np - (J + W)
+            if rows <= 0:
+                break
+            nxt = b + 1
+            handle, panel_next = None, None
+            if nxt < self.nJ:
+                if self.rank == self.owner(nxt):
+                    self.eng.update_block(panel, rows, J + W, W, self.blk[nxt], self.ld, self.Np, self.start(nxt),
+                                          self.width(nxt))
+                panel_next = self._factor_and_pack(nxt)
+                if panel_next is not None:
+                    handle = self._bcast(panel_next, self.owner(nxt), async_op=True)
+                    self.bytes_broadcast += panel_next.numel() * 8
+            for c in self.owned:
+                if c > nxt:
+                    self.eng.update_block(panel, rows, J + W, W, self.blk[c], self.ld, self.Np, self.start(c),
+                                          self.width(c))
+            if handle is not None:
+                handle.wait()
+            panel = panel_next
+        info = self.info[:1].to(torch.int64)
+        if self.P > 1:
+            self.dist.all_reduce(info, op=self.dist.ReduceOp.MIN, group=self.group)
+        v = int(info.item())
+        return 0 if v == INT_MAX else v
+
+    # ---- solve_chol (GP_Utils.cpp:841-845) with the factor distributed by block columns -------
+    def solve(self, rhs):
+        """Returns B^-1 rhs (Np entries, replicated). rhs: replicated Np-vector (not modified)."""
+        eng = self.eng
+        xw = rhs.clone() if self.rank == 0 else eng.zeros(self.Np)
+        z = eng.zeros(self.Np)
+        for b in range(self.nJ):
+            J, W = self.start(b), self.width(b)
+            self._allreduce(xw[J:J + W])
+            if self.rank == self.owner(b):
+                eng.trsv_fwd_block(self.blk[b], self.ld, self.Np, J, W, self.inv[b], xw, z)
+        self._allreduce(z)
+        x = eng.zeros(self.Np)
+        s = eng.empty(self.nb)
+        for b in range(self.nJ - 1, -1, -1):
+            J, W = self.start(b), self.width(b)
+            if self.rank == self.owner(b):
+                if J + W < self.Np:
+                    eng.coldot(self.blk[b], self.ld, self.Np, J, W, x, s)
+                    z[J:J + W] -= s[:W]
+                eng.trsv_bwd_block(self.blk[b], self.ld, J, W, self.inv[b], z, x)
+            self._bcast(x[J:J + W], self.owner(b))
+        return x
+
+    # ---- GP_utils::logLikelihood (GP_Utils.cpp:1138-1162) ----------------------------------------
+    def nlz(self):
+        torch = _torch()
+        e, bias, sn2, mode = self.params
+        self.fill()
+        bad = self.factor()
+        if bad:
+            return math.nan  # Chol_fail -> quiet NaN, GP_Utils.cpp:1145-1158
+        self.alpha = self.solve(self.y / sn2)  # alpha = (K + sn2 I)^-1 y
+        # f = K*alpha: each rank sums over its slice of source points, then one all-reduce
+        per = (self.N + self.P - 1) // self.P
+        per = (per + 1) // 2 * 2
+        i0, i1 = min(self.N, self.rank * per), min(self.N, (self.rank + 1) * per)
+        f = self.eng.zeros(self.Np)
+        if i1 > i0:
+            self.eng.kmatvec(self.u, self.cap, self.N, i0, i1, self.alpha, e, bias, mode, self.scratch, f)
+        self._allreduce(f)
+        ld_local = self.eng.zeros(1)
+        for b in self.owned:
+            self.eng.logdiag_block(self.blk[b], self.ld, self.start(b), self.width(b), self.N, self.small[4:5])
+            ld_local += self.small[4:5]
+        self._allreduce(ld_local)
+        self.eng.nlz_terms(self.N, self.y, f, self.alpha, sn2, self.small[0:2])
+        vals = torch.cat([self.small[0:2], ld_local]).cpu().numpy()
+        self.quad, self.sumlp, self.logdet = float(vals[0]), float(vals[1]), float(vals[2])
+        return self.quad - self.sumlp + self.logdet  # GP_Utils.cpp:1159
+
+    def get_alpha(self):
+        return self.alpha[:self.N].cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus N entry point (launched by torch.distributed.run, one rank per GPU)
+# ------------------------------------------------------------------------------------------------
+def bench(args):
+    torch = _torch()
+    import torch.distributed as dist
+    from . import synth
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); "
+                         f"got WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    eng = HipEngine(local)
+    N = args.n
+    X, y = synth.drillholes(N)
+    gp = DistGP(eng, X, y, nb=args.nb_outer or 512)
+    mode = 1 if args.dist == "direct" else 0
+    import bench as bench_mod
+
+    def step(i):
+        e, bias, sn2 = bench_mod.params_for_step(i)
+        gp.set_params(e, bias, sn2, mode)
+        return gp.nlz()
+
+    for i in range(args.warmup):
+        step(i)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nlz = None
+    for i in range(args.steps):
+        nlz = step(args.warmup + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=eng.device)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall = float(wall.item())
+    out = None
+    if rank == 0:
+        flops = gp.Np ** 3 / 3.0
+        out = {
+            "metric": "GP train step/sec (Gram+Cholesky+logML) at N=32768 fp64",
+            "value": args.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N={N} fp64 ExpAns+Bias Gram + block-column-cyclic Cholesky + solves + logML, "
+                                   f"panel broadcast over RCCL", "N": N, "dist_mode": args.dist,
+                       "nb_outer": gp.nb, "parallelism": f"block-column-cyclic x{world}"},
+            "nlz": nlz,
+            "roofline": {"kernel": "gpak_gemm_nt_f64<true> (trailing update)", "bound": "mfma",
+                         "achieved": flops / (wall / args.steps) / 1e12 / world,
+                         "peak": bench_mod.PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (wall / args.steps) / 1e12 / world / bench_mod.PEAK_F64_MFMA_TFLOPS,
+                         "traffic": None,
+                         "note": "whole-step N^3/3 flops per GPU over the step time (not a per-kernel figure)"},
+            "bytes_broadcast_per_step": gp.bytes_broadcast,
+        }
+    dist.destroy_process_group()
+    return out

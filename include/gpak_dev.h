@@ -1,0 +1,68 @@
+/*
+ * gpak_dev.h -- device-pointer level C-ABI of libgpak_hip.so: the per-GPU tile operations of
+ * the multi-GPU (block-column-cyclic) factorisation and solves.  The reference is a single
+ * process with no distribution at all; these entry points are the pieces of
+ * GP_utils::ldB2_exact / solve_chol / logLikelihood (GP_Utils.cpp:841-845, 872-915, 1138-1162)
+ * that one rank executes on the block columns it owns.  One process per GPU calls them
+ * between torch.distributed (RCCL over xGMI) collectives: gp_ss_ak_amd/multigpu.py.
+ *
+ * All pointers are DEVICE pointers owned by the caller (e.g. torch tensors); `stream` is a
+ * hipStream_t (NULL = the default stream).  Calls only enqueue work; they do not synchronise.
+ * Matrices are column-major doubles.  A rank stores a block column [J, J+W) of the N x N
+ * matrix as an (Np x W) array with leading dimension ld whose column 0 is global column J;
+ * Np = N rounded up to 128, padded rows/columns form an identity block.
+ * Every function returns GPAK_OK or a negative HIP status.
+ */
+#ifndef GPAK_DEV_H
+#define GPAK_DEV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* u = (x - mu) * sigInv for the N points, SoA: u is 4*cap doubles {u0[cap],u1[cap],u2[cap],|u|^2[cap]}.
+ * x is SoA with stride xs.  mu[3] is the pooled mean (Kernel.cpp:1391-1392), expans[8] as gpak_set_params. */
+int gpak_dev_transform(void *stream, const double *x, int xs, int n, int cap, const double *expans,
+                       const double *mu, double *u);
+
+/* Fill the lower tiles of B = I + K/sn2 (GP_Utils.cpp:898-902) for global columns [J, J+W)
+ * into blk (column 0 of blk = global column J).  u/cap/n as produced by gpak_dev_transform. */
+int gpak_dev_fill_b(void *stream, const double *u, int cap, int n, int Np, int J, int W,
+                    const double *expans, double bias, double sn2, int dist_mode, double *blk, long ld);
+
+/* Factor block column [J, J+W) in place: its W x W diagonal block (128 columns at a time) and
+ * the panel below.  inv receives (W/128) x 2 x 128 x 128 doubles (inverse and inverse-transpose
+ * of each 128 x 128 diagonal block).  *info (device int, pre-set to INT_MAX by the caller)
+ * gets the minimum failing global column (1-based) if the block is not positive definite. */
+int gpak_dev_factor_panel(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info);
+
+/* Trailing update of an owned block column [Jc, Jc+Wc), Jc > J, with the factored panel of
+ * [J, J+W) received from its owner.  `panel` holds rows [J+W.., Np) of that block column packed
+ * with leading dimension ldp: panel[(r - prow0) + k*ldp] = L[r, J+k], prow0 = first packed row. */
+int gpak_dev_update_block(void *stream, const double *panel, long ldp, int prow0, int W, double *blk, long ld,
+                          int Np, int Jc, int Wc);
+
+/* Forward substitution step for block column [J, J+W):  out[J..J+W) = L_bb^-1 x[J..J+W) and
+ * x[r] -= L[r, J..J+W) out  for every r >= J+W.  x, out have Np entries. */
+int gpak_dev_trsv_fwd_block(void *stream, const double *blk, long ld, int Np, int J, int W, const double *inv,
+                            double *x, double *out);
+/* s[0..W) = sum_{r >= J+W} L[r, J+c] x[r]   (the owner-local part of the back substitution) */
+int gpak_dev_coldot(void *stream, const double *blk, long ld, int Np, int J, int W, const double *x, double *s);
+/* out[J..J+W) = L_bb^-T x[J..J+W)  (x[J..J+W) is overwritten with intermediates) */
+int gpak_dev_trsv_bwd_block(void *stream, const double *blk, long ld, int J, int W, const double *inv, double *x,
+                            double *out);
+/* out[0] = sum of log L[c,c] over the valid (c < N) columns of the block column */
+int gpak_dev_logdiag_block(void *stream, const double *blk, long ld, int J, int W, int N, double *out);
+
+/* out[j] = sum_{i in [i0,i1)} w[i] k(x_i, x_j), j < n: one rank's share of f = K*alpha (GP_Utils.cpp:1147).
+ * scratch must hold 64*cap doubles. */
+int gpak_dev_kmatvec(void *stream, const double *u, int cap, int n, int i0, int i1, const double *w,
+                     const double *expans, double bias, int dist_mode, double *scratch, double *out);
+/* out[0] = Alpha'(0.5 f), out[1] = accu(lp)   (GP_Utils.cpp:810, 1159) */
+int gpak_dev_nlz_terms(void *stream, int N, const double *y, const double *f, const double *alpha, double sn2,
+                       double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

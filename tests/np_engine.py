@@ -1,0 +1,124 @@
+"""CPU stand-in for HipEngine, TEST INFRASTRUCTURE ONLY (uses numpy/scipy and the oracle's sigInv).
+
+It lets the world_size>1 gloo tests drive gp_ss_ak_amd.multigpu.DistGP -- the ownership map, the
+look-ahead schedule, the panel pack/broadcast and the solve collectives -- on a machine without
+a GPU.  It mirrors the semantics of include/gpak_dev.h function by function.
+"""
+import numpy as np
+import scipy.linalg as sl
+import torch
+
+TILE = 128
+
+
+class NumpyEngine:
+    def empty(self, n, dtype=None):
+        return torch.zeros(int(n), dtype=dtype or torch.float64)
+
+    zeros = empty
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a).copy())
+
+    def sync(self):
+        pass
+
+    @staticmethod
+    def _A(expans):
+        from oracle import oracle as orc
+        par = [expans[0], expans[2], expans[4], expans[1], expans[3], expans[5]]
+        return orc.siginv(par)
+
+    def transform(self, x_soa, xs, n, cap, expans, mu, u):
+        X = x_soa.numpy().reshape(3, xs)[:, :n].T
+        U = (X - np.asarray(mu)[None, :]) @ self._A(expans)
+        un = u.numpy().reshape(4, cap)
+        un[:] = 0
+        un[:3, :n] = U.T
+        un[3, :n] = (U * U).sum(1)
+
+    @staticmethod
+    def _kfun(un, rows, cols, expans, bias, mode):
+        P, Q = un[:3, rows].T, un[:3, cols].T
+        if mode == 1:
+            D2 = ((P[:, None, :] - Q[None, :, :]) ** 2).sum(-1)
+        else:
+            D2 = un[3, rows][:, None] + un[3, cols][None, :] - 2 * P @ Q.T
+            D2[D2 < 0] = 0
+        return expans[6] ** 2 * np.exp(-np.sqrt(D2)) + bias
+
+    def fill_b(self, u, cap, n, Np, J, W, expans, bias, sn2, mode, blk, ld):
+        un = u.numpy().reshape(4, cap)
+        M = blk.numpy().reshape(W, ld).T  # (ld x W) column-major view
+        M[:Np, :] = 0
+        nc = max(0, min(W, n - J))
+        if nc > 0:
+            M[:n, :nc] = self._kfun(un, slice(0, n), slice(J, J + nc), expans, bias, mode) / sn2
+        for c in range(W):
+            M[J + c, c] += 1.0
+
+    def factor_panel(self, blk, ld, Np, J, W, inv, info):
+        M = blk.numpy().reshape(W, ld).T
+        D = np.tril(M[J:J + W, :])
+        D = D + np.tril(D, -1).T
+        try:
+            L = sl.cholesky(D, lower=True)
+        except sl.LinAlgError:
+            # leading minor that fails, 1-based global column
+            k = next(i for i in range(1, W + 1) if np.linalg.eigvalsh(D[:i, :i]).min() <= 0)
+            info[0] = min(int(info[0]), J + k)
+            L = np.eye(W)
+        M[J:J + W, :] = L
+        if J + W < Np:
+            M[J + W:Np, :] = sl.solve_triangular(L, M[J + W:Np, :].T, lower=True).T
+        iv = inv.numpy().reshape(W // TILE, 2, TILE, TILE)
+        for k in range(W // TILE):
+            X = np.linalg.inv(L[k * TILE:(k + 1) * TILE, k * TILE:(k + 1) * TILE])
+            iv[k, 0] = X.T   # stored column-major: memory [c][r] = X[r][c]
+            iv[k, 1] = X     # inverse transpose, column-major
+
+    def update_block(self, panel, ldp, prow0, W, blk, ld, Np, Jc, Wc):
+        P = panel.numpy().reshape(W, ldp).T
+        C = blk.numpy().reshape(Wc, ld).T
+        a = P[Jc - prow0:Np - prow0, :]
+        C[Jc:Np, :] -= a @ a[:Wc, :].T
+
+    def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out):
+        M = blk.numpy().reshape(W, ld).T
+        iv = inv.numpy().reshape(W // TILE, 2, TILE, TILE)
+        xn, on = x.numpy(), out.numpy()
+        for k in range(W // TILE):
+            j0 = J + k * TILE
+            z = iv[k, 0].T @ xn[j0:j0 + TILE]
+            on[j0:j0 + TILE] = z
+            xn[j0 + TILE:Np] -= M[j0 + TILE:Np, k * TILE:(k + 1) * TILE] @ z
+
+    def coldot(self, blk, ld, Np, J, W, x, s):
+        M = blk.numpy().reshape(W, ld).T
+        s.numpy()[:W] = M[J + W:Np, :].T @ x.numpy()[J + W:Np]
+
+    def trsv_bwd_block(self, blk, ld, J, W, inv, x, out):
+        M = blk.numpy().reshape(W, ld).T
+        iv = inv.numpy().reshape(W // TILE, 2, TILE, TILE)
+        xn, on = x.numpy(), out.numpy()
+        for k in range(W // TILE - 1, -1, -1):
+            j0 = J + k * TILE
+            w = iv[k, 1].T @ xn[j0:j0 + TILE]      # inv(L_jj)^T x_j
+            on[j0:j0 + TILE] = w
+            if k > 0:
+                xn[J:j0] -= M[j0:j0 + TILE, :k * TILE].T @ w
+
+    def logdiag_block(self, blk, ld, J, W, N, out):
+        M = blk.numpy().reshape(W, ld).T
+        nc = max(0, min(W, N - J))
+        out[0] = float(np.log(np.diag(M[J:J + nc, :nc])).sum()) if nc else 0.0
+
+    def kmatvec(self, u, cap, n, i0, i1, w, expans, bias, mode, scratch, out):
+        un = u.numpy().reshape(4, cap)
+        K = self._kfun(un, slice(i0, i1), slice(0, n), expans, bias, mode)
+        out.numpy()[:n] = w.numpy()[i0:i1] @ K
+
+    def nlz_terms(self, N, y, f, alpha, sn2, out):
+        yn, fn, an = y.numpy()[:N], f.numpy()[:N], alpha.numpy()[:N]
+        out[0] = float((an * 0.5 * fn).sum())
+        out[1] = float((-(yn - fn) ** 2 / (2 * sn2) - np.log(2 * np.pi * sn2) / 2).sum())
