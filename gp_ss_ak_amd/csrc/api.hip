@@ -73,7 +73,9 @@ static void release_train(gpak_ctx *ctx) {
   if (ctx->dInv) hipFree(ctx->dInv);
   if (ctx->dAlpha) hipFree(ctx->dAlpha);
   if (ctx->dWork) hipFree(ctx->dWork);
-  ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dAlpha = ctx->dWork = nullptr;
+  if (ctx->dF) hipFree(ctx->dF);
+  gpak_grad_release(ctx);
+  ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dAlpha = ctx->dWork = ctx->dF = nullptr;
   free_points(ctx->U);
   ctx->N = ctx->Np = 0;
   ctx->mstate = gpak_ctx::M_NONE;
@@ -177,6 +179,7 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
       hipMalloc(&ctx->dM, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
       hipMalloc(&ctx->dInv, sizeof(double) * (size_t)T * 2 * GPAK_TILE * GPAK_TILE) != hipSuccess ||
       hipMalloc(&ctx->dAlpha, sizeof(double) * (size_t)Np) != hipSuccess ||
+      hipMalloc(&ctx->dF, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dWork, sizeof(double) * 70 * (size_t)Np) != hipSuccess) {
     ctx->err = "device allocation failed for the training set";
     release_train(ctx);
@@ -286,7 +289,7 @@ static int ensure_nlz(gpak_ctx *ctx) {
   if (rc) return rc;
   if (ctx->nlz_ok) return GPAK_OK;
   hipStream_t st = ctx->stream;
-  double *f = ctx->dWork + 2 * (size_t)ctx->Np;
+  double *f = ctx->dF;
   double *scratch = ctx->dWork + 4 * (size_t)ctx->Np;  // 64 * Np doubles available
   GPAK_HIP(hipEventRecord(ctx->ev[5], st));
   int splits = gpak_kmatvec_splits(ctx->N, ctx->N);

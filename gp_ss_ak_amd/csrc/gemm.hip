@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
                                                             const double *A, long lda, const double *B,
                                                             long ldb,
                                                             double beta, double *C, long ldc, int rb0,
-                                                            int cb0, int lower_skip, int mt, int nt) {
+                                                            int cb0, int lower_skip, int mt, int nt, int k0_by_row) {
   // Workgroup -> tile map, XCD-aware: the dispatcher deals consecutive workgroup ids round-robin
   // over the 8 XCDs, so id b runs on XCD (b & 7) as that XCD's (b >> 3)-th workgroup.  Each XCD
   // walks 8x8 super-tiles: the 64 workgroups resident on its 32 CUs (2 per CU) cover one
@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
                                      16, 0, 0);                                                   \
   }
 
-  GPAK_STAGE(0, 0)
+  // k0_by_row: A (and B) are upper triangular in (row, k), so tile row ti only has k >= ti*128
+  const int st_begin = k0_by_row ? (rb0 + ti) * (TM / KB) : 0;
+  GPAK_STAGE(st_begin & 1, (size_t)st_begin * KB)
   __syncthreads();  // emits vmcnt(0) for the in-flight LDS-DMA, then the barrier
 
 #define GPAK_COMPUTE(buf_)                                                                          \
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
             acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0); \
   }
 
-  for (int st = 0; st + 1 < nstage; st++) {
+  for (int st = st_begin; st + 1 < nstage; st++) {
     const int buf = st & 1;
     // stage st+1 streams into the other buffer while this stage's MFMAs run
     GPAK_STAGE(buf ^ 1, (size_t)(st + 1) * KB)
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
 
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
-                         int col_block0, bool lower_skip, bool trailing) {
+                         int col_block0, bool lower_skip, bool trailing, bool k0_by_row) {
   if (mt <= 0 || nt <= 0) return;
   const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
   long nsuper = 0;
@@ -164,10 +166,10 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   if (trailing)
     hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0);
   else
     hipLaunchKernelGGL(gpak_gemm_nt_f64<false>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------

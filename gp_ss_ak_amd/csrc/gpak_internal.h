@@ -69,6 +69,13 @@ struct gpak_ctx {
   int pred_cap = 0;
   size_t wt_elems = 0;
 
+  // gradient buffers (allocated on the first gpak_grad)
+  double *dG = nullptr;      // Np x ld: L^-T (upper triangular)
+  double *dBinv = nullptr;   // Np x ld: B^-1, lower tiles
+  double *dF = nullptr;      // Np: f = K*alpha of the last logLikelihood()
+  double *dGpart = nullptr;  // per-workgroup partial sums of the pair pass
+  size_t gpart_elems = 0;
+
   // options
   bool memoise = false;
   int nb_outer = 512;
@@ -108,6 +115,7 @@ void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, const double *w, co
 void gpak_launch_sum_splits(hipStream_t st, const double *part, int part_ld, int splits, int n, double *out);
 int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap);
 void gpak_pooled_mean(const double *s1, long n, const double *s2, long m, double *mu);
+int gpak_ensure_U(gpak_ctx *ctx);
 
 // ---- gemm.hip ---------------------------------------------------------------------------
 // C[mt x nt tiles of 128] = beta*C + alpha * A (m x K) * B (n x K)^T, all column-major.
@@ -115,7 +123,7 @@ void gpak_pooled_mean(const double *s1, long n, const double *s2, long m, double
 // trailing=true selects the instantiation named gpak_syrk_trailing_f64 (profiling only).
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
-                         int col_block0, bool lower_skip, bool trailing);
+                         int col_block0, bool lower_skip, bool trailing, bool k0_by_row = false);
 
 // ---- potrf.hip --------------------------------------------------------------------------
 // Factor the 128x128 block at A (ld) in place (lower), write its inverse to inv (128x128, ld 128).
@@ -146,3 +154,6 @@ void gpak_launch_scale(hipStream_t st, int n, const double *in, double s, double
 
 // ---- predict.hip ------------------------------------------------------------------------
 void gpak_predict_release(gpak_ctx *ctx);
+
+// ---- grad.hip ---------------------------------------------------------------------------
+void gpak_grad_release(gpak_ctx *ctx);

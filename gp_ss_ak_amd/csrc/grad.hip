@@ -1,0 +1,299 @@
+// grad.hip -- the reference-style "gradient" of the negative log marginal likelihood on gfx950.
+//
+// Replaces GP_utils::GradLL / dhyp / updateG / updateGlikelihood (GP_Utils.cpp:846-864,
+// 1164-1284) with Kern_ExpAnisotropic::getGradients (Kernel.cpp:886-1263) and
+// Kern_Bias::getGradients (:370-377), FORMULAS AS WRITTEN (this is not the
+// true gradient -- the optimiser trajectory of the reference depends on it as it is).
+//
+// Reference: Q = solve_chol(Lchol, diag(sW)) with N right-hand sides (2N^3 flops), ~15 N x N
+// temporaries, six N x 3 * 3 x N GEMMs.  Here, for the Gaussian likelihood (d3lp = 0, so
+// dfhat = dahat = 0, GP_Utils.cpp:414, 1210-1219):
+//   1. G = L^-T by blocked forward substitution on the identity, touching only the rows that
+//      can be non-zero (N^3/3 flops, MFMA);
+//   2. B^-1 = G G^T, lower tiles, k-loop started at the row tile (N^3/3 flops, MFMA);
+//   3. ONE fused pass over the pairs i >= j that recomputes K_ij from the coordinates and
+//      accumulates the nine sums the ten gradient entries are made of.
+#include <cmath>
+#include <vector>
+
+#include "gpak_internal.h"
+
+#define PB 128
+#define GT_ROWS 128
+#define GT_COLS 64
+#define NSUM 9
+
+struct GradConsts {
+  double M[6][6];   // S % S_p, symmetric 3x3 stored as {00,01,02,11,12,22}, p = 0..5
+  double m2[6][3];  // 2 * column sums of M_p : a_i^(p) = sum_k x_ik^2 m2[p][k]
+  double var2, bias, sn2;
+  int mode;
+};
+
+__global__ void gpak_identity_f64(double *W, long ld, int n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)n * ld;
+  if (i >= tot) return;
+  const size_t c = i / ld, r = i - c * ld;
+  W[i] = (r == c) ? 1.0 : 0.0;
+}
+
+// pair pass over the lower triangle; block partials: part[block][NSUM]
+__global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
+    const double *__restrict__ u0, const double *__restrict__ u1, const double *__restrict__ u2,
+    const double *__restrict__ us, const double *__restrict__ x0, const double *__restrict__ x1,
+    const double *__restrict__ x2, const double *__restrict__ alpha, const double *__restrict__ Binv, long ld,
+    int N, GradConsts gc, double *__restrict__ part) {
+  const int row0 = blockIdx.x * GT_ROWS, col0 = blockIdx.y * GT_COLS;
+  const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+  __shared__ double cq[5][GT_COLS];        // u0,u1,u2,|u|^2, alpha of the column points
+  __shared__ double cm[6][3][GT_COLS];     // M_p x_j
+  __shared__ double ca[6][GT_COLS];        // a_j^(p)
+  __shared__ double red[4][NSUM];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  double acc[NSUM];
+#pragma unroll
+  for (int k = 0; k < NSUM; k++) acc[k] = 0.0;
+  if (row0 + GT_ROWS > col0) {  // tile touches the lower triangle
+    if (t < GT_COLS) {
+      const int j = col0 + t;
+      const bool ok = j < N;
+      cq[0][t] = ok ? u0[j] : 0.0; cq[1][t] = ok ? u1[j] : 0.0; cq[2][t] = ok ? u2[j] : 0.0;
+      cq[3][t] = ok ? us[j] : 0.0; cq[4][t] = ok ? alpha[j] : 0.0;
+      const double a = ok ? x0[j] : 0.0, b = ok ? x1[j] : 0.0, c = ok ? x2[j] : 0.0;
+#pragma unroll
+      for (int p = 0; p < 6; p++) {
+        const double *M = gc.M[p];
+        cm[p][0][t] = M[0] * a + M[1] * b + M[2] * c;
+        cm[p][1][t] = M[1] * a + M[3] * b + M[4] * c;
+        cm[p][2][t] = M[2] * a + M[4] * b + M[5] * c;
+        ca[p][t] = a * a * gc.m2[p][0] + b * b * gc.m2[p][1] + c * c * gc.m2[p][2];
+      }
+    }
+    __syncthreads();
+    const int r = row0 + 2 * lane;
+    double pu[2][4], px[2][3], pa[2][6], pal[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int i = r + h;
+      const bool ok = i < N;
+      pu[h][0] = ok ? u0[i] : 0.0; pu[h][1] = ok ? u1[i] : 0.0; pu[h][2] = ok ? u2[i] : 0.0;
+      pu[h][3] = ok ? us[i] : 0.0;
+      px[h][0] = ok ? x0[i] : 0.0; px[h][1] = ok ? x1[i] : 0.0; px[h][2] = ok ? x2[i] : 0.0;
+      pal[h] = ok ? alpha[i] : 0.0;
+#pragma unroll
+      for (int p = 0; p < 6; p++)
+        pa[h][p] = px[h][0] * px[h][0] * gc.m2[p][0] + px[h][1] * px[h][1] * gc.m2[p][1] +
+                   px[h][2] * px[h][2] * gc.m2[p][2];
+    }
+    for (int c = 0; c < GT_COLS / 4; c++) {
+      const int jl = w + 4 * c, j = col0 + jl;
+      if (j >= N) continue;
+      const double2 q2 = *reinterpret_cast<const double2 *>(Binv + r + (size_t)j * ld);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int i = r + h;
+        if (i >= N || i < j) continue;
+        const double q = h ? q2.y : q2.x;
+        const double wgt = (i == j) ? 1.0 : 2.0;  // every summand is symmetric in (i, j)
+        double d2;
+        if (gc.mode == GPAK_DIST_DIRECT) {
+          const double a = pu[h][0] - cq[0][jl], b = pu[h][1] - cq[1][jl], cc = pu[h][2] - cq[2][jl];
+          d2 = a * a + b * b + cc * cc;
+        } else {
+          const double dot = pu[h][0] * cq[0][jl] + pu[h][1] * cq[1][jl] + pu[h][2] * cq[2][jl];
+          d2 = pu[h][3] + cq[3][jl] - 2.0 * dot;
+          d2 = d2 < 0.0 ? 0.0 : d2;
+        }
+        const double sd = sqrt(d2);                       // Kernel.cpp:1178
+        const double ek = exp(-1.0 * sd);                 // KD2, :1176
+        const double qw = q * (1.0 / gc.sn2) - pal[h] * cq[4][jl];   // dhyp, GP_Utils.cpp:1168
+        double dk = (sd == 0.0 || i == j) ? 0.0 : ek * (-0.5 / sd);  // :1179-1184
+        const double rm = gc.var2 * qw * dk;              // R = Qs % dk, :927, :1185
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+          const double xmx = px[h][0] * cm[p][0][jl] + px[h][1] * cm[p][1][jl] + px[h][2] * cm[p][2][jl];
+          const double di2 = pa[h][p] + ca[p][jl] - 4.0 * xmx;   // Di2, :1192-1194
+          acc[p] = fma(wgt * rm, di2, acc[p]);
+        }
+        acc[6] = fma(wgt * qw, ek, acc[6]);                                  // :1239-1241
+        acc[7] = fma(wgt * q, gc.var2 * ek + gc.bias, acc[7]);               // sum(Q % K), GP_Utils.cpp:1206
+        if (i == j) acc[8] += qw;                                            // trace(QW), Kernel.cpp:370-377
+      }
+    }
+  }
+  // block reduction (fixed order)
+#pragma unroll
+  for (int k = 0; k < NSUM; k++) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) red[w][k] = v;
+  }
+  __syncthreads();
+  if (t < NSUM) part[(size_t)bid * NSUM + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
+__global__ __launch_bounds__(256) void gpak_grad_reduce_f64(const double *__restrict__ part, int nblocks,
+                                                            double *__restrict__ out) {
+  __shared__ double sh[256];
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(size_t)b * NSUM + k];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[k] = sh[0];
+}
+
+// sum_i ((y_i - f_i)^2 / sn2 - 1)    (lp_dhyp, GP_Utils.cpp:858)
+__global__ __launch_bounds__(1024) void gpak_lpdhyp_f64(int N, const double *__restrict__ y,
+                                                         const double *__restrict__ f, double sn2, double *out) {
+  __shared__ double sh[1024];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double d = y[i] - f[i];
+    s += (1.0 / sn2) * d * d - 1.0;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+void gpak_grad_release(gpak_ctx *ctx) {
+  if (ctx->dG) hipFree(ctx->dG);
+  if (ctx->dBinv) hipFree(ctx->dBinv);
+  if (ctx->dGpart) hipFree(ctx->dGpart);
+  ctx->dG = ctx->dBinv = ctx->dGpart = nullptr;
+  ctx->gpart_elems = 0;
+}
+
+// S, S_alpha.. as written at Kernel.cpp:955-1166 (the (0,0) z-term of the angle derivatives lacks
+// its factor 2, :1003-1011) and M_p = S % S_p
+static void build_grad_consts(const double *e, GradConsts &gc) {
+  const double al = e[0], be = e[2], te = e[4];
+  const double iw[3] = {e[1], e[3], e[5]};
+  const double ca = cos(al), sa = sin(al), cb = cos(be), sb = sin(be), ct = cos(te), st = sin(te);
+  double R[3][3], D[3][3][3];
+  R[0][0] = ca * ct + sa * sb * st;   D[0][0][0] = -sa * ct + ca * sb * st;
+  D[1][0][0] = sa * cb * st;          D[2][0][0] = -ca * st + sa * sb * ct;
+  R[0][1] = -sa * ct + ca * sb * st;  D[0][0][1] = -ca * ct - sa * sb * st;
+  D[1][0][1] = ca * cb * st;          D[2][0][1] = sa * st + ca * sb * ct;
+  R[0][2] = -cb * st;                 D[0][0][2] = 0.0;
+  D[1][0][2] = sb * st;               D[2][0][2] = -cb * ct;
+  R[1][0] = sa * cb;                  D[0][1][0] = ca * cb;
+  D[1][1][0] = -sa * sb;              D[2][1][0] = 0.0;
+  R[1][1] = ca * cb;                  D[0][1][1] = -sa * cb;
+  D[1][1][1] = -ca * sb;              D[2][1][1] = 0.0;
+  R[1][2] = sb;                       D[0][1][2] = 0.0;
+  D[1][1][2] = cb;                    D[2][1][2] = 0.0;
+  R[2][0] = ca * st - sa * sb * ct;   D[0][2][0] = -sa * st - ca * sb * ct;
+  D[1][2][0] = -sa * cb * ct;         D[2][2][0] = ca * ct + sa * sb * st;
+  R[2][1] = -sa * st - ca * sb * ct;  D[0][2][1] = -ca * st + sa * sb * ct;
+  D[1][2][1] = -ca * cb * ct;         D[2][2][1] = -sa * ct + ca * sb * st;
+  R[2][2] = cb * ct;                  D[0][2][2] = 0.0;
+  D[1][2][2] = -sb * ct;              D[2][2][2] = -cb * st;
+  double S[3][3], Sp[6][3][3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += iw[k] * R[r][k] * R[c][k];
+      S[r][c] = s;
+      for (int a = 0; a < 3; a++) {
+        double t = 0.0;
+        for (int k = 0; k < 3; k++) {
+          double term = iw[k] * (D[a][r][k] * R[c][k] + R[r][k] * D[a][c][k]);
+          if (r == 0 && c == 0 && k == 2) term *= 0.5;
+          t += term;
+        }
+        Sp[2 * a][r][c] = t;
+        Sp[2 * a + 1][r][c] = R[r][a] * R[c][a];
+      }
+    }
+  const int ir[6] = {0, 0, 0, 1, 1, 2}, ic[6] = {0, 1, 2, 1, 2, 2};
+  for (int p = 0; p < 6; p++) {
+    double M[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) M[r][c] = S[r][c] * Sp[p][r][c];
+    for (int q = 0; q < 6; q++) gc.M[p][q] = M[ir[q]][ic[q]];
+    for (int k = 0; k < 3; k++) gc.m2[p][k] = 2.0 * (M[k][0] + M[k][1] + M[k][2]);
+  }
+}
+
+int gpak_grad_impl(gpak_ctx *ctx, double *g) {
+  GPAK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int N = ctx->N, Np = ctx->Np, T = Np / PB;
+  const long ld = ctx->ld;
+  if (!ctx->dG) {
+    if (hipMalloc(&ctx->dG, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
+        hipMalloc(&ctx->dBinv, sizeof(double) * (size_t)ld * Np) != hipSuccess) {
+      ctx->err = "device allocation failed for the gradient workspaces (2 N x N matrices)";
+      gpak_grad_release(ctx);
+      return GPAK_ENOMEM;
+    }
+  }
+  GPAK_HIP(hipEventRecord(ctx->ev[7], st));
+  // 1. G = L^-T: forward substitution on the identity, rows restricted to the non-zero part
+  double *G = ctx->dG;
+  {
+    const size_t tot = (size_t)Np * ld;
+    hipLaunchKernelGGL(gpak_identity_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, G, ld, Np);
+  }
+  for (int jb = 0; jb < T; jb++) {
+    const size_t j0 = (size_t)jb * PB;
+    const double *inv = ctx->dInv + (size_t)jb * 2 * PB * PB;
+    double *Gj = G + j0 * ld;
+    const int mt = jb + 1;  // rows 0 .. j0+127: everything below is zero in L^-T
+    gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Gj, ld, inv, PB, 0.0, Gj, ld, 0, 0, false, false);
+    const int nrest = T - jb - 1;
+    if (nrest > 0)
+      gpak_launch_gemm_nt(st, mt, nrest, PB, -1.0, Gj, ld, ctx->dM + (j0 + PB) + j0 * ld, ld, 1.0,
+                          G + (j0 + PB) * ld, ld, 0, 0, false, false);
+  }
+  // 2. B^-1 = G G^T (lower tiles); G[i,k] = 0 for k < i, so the k-loop starts at the row tile
+  gpak_launch_gemm_nt(st, T, T, Np, 1.0, G, ld, G, ld, 0.0, ctx->dBinv, ld, 0, 0, true, true, true);
+  // 3. fused pair pass
+  GradConsts gc;
+  build_grad_consts(ctx->expans, gc);
+  gc.var2 = ctx->kp.var2; gc.bias = ctx->bias; gc.sn2 = ctx->sn2; gc.mode = ctx->dist_mode;
+  dim3 grid(Np / GT_ROWS, Np / GT_COLS);
+  const size_t nblocks = (size_t)grid.x * grid.y;
+  if (ctx->gpart_elems < nblocks * NSUM) {
+    if (ctx->dGpart) hipFree(ctx->dGpart);
+    ctx->dGpart = nullptr; ctx->gpart_elems = 0;
+    if (hipMalloc(&ctx->dGpart, sizeof(double) * nblocks * NSUM) != hipSuccess) {
+      ctx->err = "device allocation failed for gradient partial sums";
+      return GPAK_ENOMEM;
+    }
+    ctx->gpart_elems = nblocks * NSUM;
+  }
+  int rc = gpak_ensure_U(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, ctx->U.u0, ctx->U.u1, ctx->U.u2, ctx->U.s,
+                     ctx->dX, ctx->dX + Np, ctx->dX + 2 * (size_t)Np, ctx->dAlpha, ctx->dBinv, ld, N, gc,
+                     ctx->dGpart);
+  hipLaunchKernelGGL(gpak_grad_reduce_f64, dim3(NSUM), dim3(256), 0, st, ctx->dGpart, (int)nblocks, ctx->dRed + 8);
+  hipLaunchKernelGGL(gpak_lpdhyp_f64, dim3(1), dim3(1024), 0, st, N, ctx->dy, ctx->dF, ctx->sn2, ctx->dRed + 8 + NSUM);
+  double red[NSUM + 1];
+  GPAK_HIP(hipMemcpyAsync(red, ctx->dRed + 8, sizeof(red), hipMemcpyDeviceToHost, st));
+  GPAK_HIP(hipEventRecord(ctx->ev[3], st));
+  GPAK_HIP(hipEventSynchronize(ctx->ev[3]));
+  float ms = 0;
+  GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[3]));
+  ctx->times.grad_ms = ms;
+  for (int p = 0; p < 6; p++) g[p] = red[p];                 // Kernel.cpp:1195-1233
+  g[6] = 2.0 * red[6] * ctx->expans[6];                      // :1241-1242
+  g[7] = 0.0;                                                // :1256-1257 (3-D)
+  g[8] = red[8];                                             // Kern_Bias::getGradients
+  const double sum_dW = 0.5 * red[7];                        // dW = 0.5 * sum(Q % K, 1)
+  g[9] = -1.0 * sum_dW * (2.0 / ctx->sn2) - red[9];          // GP_Utils.cpp:1226
+  return GPAK_OK;
+}

@@ -173,8 +173,3 @@ int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k) {
   return GPAK_OK;
 }
 
-int gpak_grad_impl(gpak_ctx *ctx, double *g) {
-  (void)g;
-  ctx->err = "gpak_grad: reference-style gradient (SURVEY.md 8(f-1)) is not built in this round";
-  return GPAK_ENOTIMPL;
-}

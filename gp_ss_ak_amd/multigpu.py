@@ -71,6 +71,15 @@ class HipEngine:
     def sync(self):
         _torch().cuda.synchronize()
 
+    has_streams = True
+
+    def panel_stream(self):
+        """High-priority side stream for the look-ahead panel work (created once)."""
+        torch = _torch()
+        if not hasattr(self, "_ps"):
+            self._ps = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._ps
+
     def _st(self):
         return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
 
@@ -219,6 +228,9 @@ class DistGP:
         torch = _torch()
         self.info.fill_(INT_MAX)
         self.bytes_broadcast = 0
+        streams = getattr(self.eng, "has_streams", False)
+        main = torch.cuda.current_stream() if streams else None
+        ps = self.eng.panel_stream() if streams else None
         panel = self._factor_and_pack(0)
         if panel is not None:
             self._bcast(panel, self.owner(0))
@@ -231,19 +243,35 @@ class DistGP:
             nxt = b + 1
             handle, panel_next = None, None
             if nxt < self.nJ:
-                if self.rank == self.owner(nxt):
-                    self.eng.update_block(panel, rows, J + W, W, self.blk[nxt], self.ld, self.Np, self.start(nxt),
-                                          self.width(nxt))
-                panel_next = self._factor_and_pack(nxt)
-                if panel_next is not None:
-                    handle = self._bcast(panel_next, self.owner(nxt), async_op=True)
-                    self.bytes_broadcast += panel_next.numel() * 8
+                # look-ahead: the next panel's owner updates + factors its column on the side stream
+                # (beside the bulk update below) and the broadcast of panel b+1 is posted by every rank
+                # before its bulk update, so the transfer overlaps the MFMA work of step b
+                if streams:
+                    ps.wait_stream(main)  # panel b is complete, earlier bulk updates of blk[nxt] are queued
+                    ctx = torch.cuda.stream(ps)
+                    ctx.__enter__()
+                try:
+                    if self.rank == self.owner(nxt):
+                        self.eng.update_block(panel, rows, J + W, W, self.blk[nxt], self.ld, self.Np,
+                                              self.start(nxt), self.width(nxt))
+                    panel_next = self._factor_and_pack(nxt)
+                    if panel_next is not None:
+                        handle = self._bcast(panel_next, self.owner(nxt), async_op=True)
+                        self.bytes_broadcast += panel_next.numel() * 8
+                finally:
+                    if streams:
+                        ctx.__exit__(None, None, None)
             for c in self.owned:
                 if c > nxt:
                     self.eng.update_block(panel, rows, J + W, W, self.blk[c], self.ld, self.Np, self.start(c),
                                           self.width(c))
             if handle is not None:
                 handle.wait()
+            if streams and nxt < self.nJ:
+                main.wait_stream(ps)
+                if panel_next is not None:
+                    panel_next.record_stream(main)
+                panel.record_stream(ps)
             panel = panel_next
         info = self.info[:1].to(torch.int64)
         if self.P > 1:

@@ -95,3 +95,22 @@ def test_not_positive_definite_reports_chol_fail(gp):
     assert math.isnan(gp.logLikelihood())            # GP_Utils.cpp:1145-1146
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)    # and the context recovers
     assert gp.factor()
+
+
+@pytest.mark.parametrize("N", [64, 512, 1000])
+@pytest.mark.parametrize("mode", [gpak.DIST_DIRECT, gpak.DIST_EXPANSION])
+def test_reference_style_gradient_matches_oracle(gp, orc, N, mode):
+    """GradLL + getGradients as written (not the true gradient: SURVEY.md 8(f-1))."""
+    X, y = synth.drillholes(N)
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, mode)
+    g = gp.GradLL()
+    Ko = orc.gram(X, X, E, BIAS, mode)
+    info, alpha_o, Lo = orc.nlz_lean(Ko, y, SN2)
+    go = orc.grad_ref(X, y, Ko, Lo, alpha_o, E, BIAS, SN2, mode)
+    scale = np.abs(go).max()
+    # the sums cancel heavily (QW = B^-1/sn2 - alpha alpha'), so the bound is relative to the
+    # largest entry; expansion mode carries the 1/sqrt(D2) amplification of the cancellation noise
+    tol = 1e-8 if mode == gpak.DIST_DIRECT else 1e-5
+    assert np.abs(g - go).max() <= tol * scale
+    assert g[7] == 0.0
