@@ -1,0 +1,121 @@
+// host_selftest.cpp -- exercises the class surface the way the reference's own call sites do
+// (gp_ss_ak.cpp:139-303, 376-412) and prints one JSON object; tests/test_host_cpp.py compares
+// it with the oracle.  Usage: host_selftest train.csv test.csv
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "control.hpp"
+#include "gp_utils.hpp"
+
+static void print_vec(const char *name, const mat &v, bool last = false) {
+  printf("\"%s\": [", name);
+  for (size_t i = 0; i < v.n_elem; i++) printf("%s%.17g", i ? ", " : "", v[i]);
+  printf("]%s\n", last ? "" : ",");
+}
+
+// CPU-only part: argument walker, data reader, the three standardisations and their inverse,
+// kernel parameter tables and the text model format -- nothing here touches the device.
+static int logic_only(const char *train_csv) {
+  char a0[] = "gp_ss_ak", a1[] = "-v", a2[] = "2", a3[] = "-pm", a4[] = "1", a5[] = "train";
+  char *cargv[] = {a0, a1, a2, a3, a4, a5, nullptr};
+  Control io(6, cargv);
+  io.setMode("train");
+  int ds[2];
+  mat X, y;
+  io.readDataSize(train_csv, ds);
+  io.readDataFile(X, y, ds, train_csv);
+  mat X0 = X, y0 = y;
+  io.prepareData(X, y, true, "/tmp/gpak_logic_model");
+  printf("{\n\"verb\": \"%s\", \"verbose\": %d, \"n\": %d, \"d\": %d,\n", io.getArg().c_str(), io.getVerbose(), ds[0], ds[1]);
+  printf("\"xmin\": %.17g, \"xmax\": %.17g, \"ymin\": %.17g, \"ymax\": %.17g,\n", X.min(), X.max(), y.min(), y.max());
+  mat Xb = X, yb = y;
+  io.postData(Xb, yb, true, "/tmp/gpak_logic_model");
+  double ex = 0, ey = 0;
+  for (size_t i = 0; i < Xb.n_elem; i++) ex = std::max(ex, std::fabs(Xb[i] - X0[i]));
+  for (size_t i = 0; i < yb.n_elem; i++) ey = std::max(ey, std::fabs(yb[i] - y0[i]));
+  printf("\"roundtrip_x\": %.3g, \"roundtrip_y\": %.3g,\n", ex, ey);
+  HybKerns Kerns(X);
+  Kern_ExpAnisotropic ea(X);
+  Kern_Bias kb(X);
+  Kerns.addNewKernel(&ea);
+  Kerns.addNewKernel(&kb);
+  Kerns.setParam(1.23456789, 1);
+  Kerns.setParam(2.0, 3);
+  std::ofstream out("/tmp/gpak_logic_kernel");
+  Kerns.StrmOut(out);
+  out.close();
+  std::ifstream in("/tmp/gpak_logic_kernel");
+  Kernels *k2 = ReadKerFromFile(in);
+  printf("\"npars\": %u, \"name8\": \"%s\", \"p1_reloaded\": %.17g, \"p3_reloaded\": %.17g, \"p8\": %.17g\n}\n",
+         k2->getNPars(), k2->getParamName(8).c_str(), k2->getParam(1), k2->getParam(3), k2->getParam(8));
+  delete k2;
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc >= 3 && std::string(argv[1]) == "--logic") return logic_only(argv[2]);
+  if (argc < 3) { fprintf(stderr, "usage: host_selftest train.csv test.csv\n"); return 2; }
+  char *cargv[] = {argv[0], nullptr};
+  Control io(1, cargv);
+  int ds[2];
+  mat X, y, Xt, yt;
+  io.readDataSize(argv[1], ds);
+  io.readDataFile(X, y, ds, argv[1]);
+  io.readDataSize(argv[2], ds);
+  io.readDataFile(Xt, yt, ds, argv[2]);
+
+  HybKerns Kerns(X);
+  Kern_ExpAnisotropic ea(X);
+  Kern_Bias kb(X);
+  Kerns.addNewKernel(&ea);
+  Kerns.addNewKernel(&kb);
+  GP_utils gp(&Kerns, X, y, GP_utils::inf_laplace, GP_utils::likeL_Gaussian, GP_utils::mean_zero, 8, 1, 0, 0);
+
+  printf("{\n\"npars\": %u,\n", gp.getNumPars());
+  mat p(1, gp.getNumPars());
+  gp.get_GP_Pars(p);
+  print_vec("params", p);
+  printf("\"param_names\": [");
+  for (unsigned i = 0; i < Kerns.getNPars(); i++) printf("%s\"%s\"", i ? ", " : "", Kerns.getParamName(i).c_str());
+  printf("],\n");
+  // Kernels::computeK on host matrices (Kernel.h:54)
+  mat K, D2;
+  Kerns.computeK(X, X, K, D2);
+  double ksum = 0;
+  for (size_t i = 0; i < K.n_elem; i++) ksum += K[i];
+  printf("\"K_sum\": %.17g,\n\"K_00\": %.17g,\n", ksum, K(0, 0));
+  mat kd(X.n_rows, 1);
+  Kerns.diag_Compute(kd, X);
+  printf("\"kdiag0\": %.17g,\n", kd(0));
+  printf("\"nlz\": %.17g,\n", gp.logLikelihood());
+  mat g(1, gp.getNumPars());
+  double f = gp.GradLL(g);
+  printf("\"nlz_from_grad\": %.17g,\n", f);
+  print_vec("grad", g);
+  mat mu(Xt.n_rows, 1), var(Xt.n_rows, 1);
+  gp.Calc_Out(mu, var, Xt);
+  print_vec("mean", mu);
+  print_vec("var", var);
+  // set_GP_Pars invalidates and a changed sn2 changes the value
+  p(9) = 0.05;
+  gp.set_GP_Pars(p);
+  printf("\"nlz_sn2_005\": %.17g,\n", gp.logLikelihood());
+  p(9) = -0.5;  // Chol_fail -> NaN
+  gp.set_GP_Pars(p);
+  double bad = gp.logLikelihood();
+  printf("\"chol_fail_is_nan\": %s,\n", bad != bad ? "true" : "false");
+  // model file round trip
+  p(9) = 0.016;
+  gp.set_GP_Pars(p);
+  writeGPFile(gp, "/tmp/gpak_selftest_model", "# GP_SS_AK Model File ");
+  GP_utils *m2 = readGpFromFile("/tmp/gpak_selftest_model", 0);
+  mat p2(1, m2->getNumPars());
+  m2->get_GP_Pars(p2);
+  print_vec("params_reloaded", p2, true);
+  printf("}\n");
+  delete m2;
+  return 0;
+}

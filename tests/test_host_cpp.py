@@ -1,0 +1,114 @@
+"""The host-side C++ mirror of the reference's class surface (gp_ss_ak_amd/host/): Kernels /
+HybKerns / GP_utils / Control and the train/test command line.
+
+CPU (-m "not gpu"): the logic that never touches the device (argument walker, data reader,
+standardisation round trip, parameter tables, text model format).
+GPU (-m gpu): the classes driven the way the reference's own call sites drive them, compared
+with the oracle; and config 1 of BASELINE.json (N=512 train + test through the CLI).
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gp_ss_ak_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gp_ss_ak_amd", "host")
+E = np.array(synth.DEFAULT_EXPANS)
+
+
+def write_csv(path, X, y, sep=","):
+    with open(path, "w") as f:
+        f.write("# x, y, z, grade\n")
+        for r, v in zip(X, y):
+            f.write(sep.join(f"{t:.17g}" for t in list(r) + [v]) + "\n")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HOST])
+
+
+def test_host_logic_without_a_gpu(tmp_path):
+    build()
+    Xr, yr = synth.drillholes_raw(200)
+    f = tmp_path / "train.txt"
+    write_csv(f, Xr, yr, sep="\t")
+    out = subprocess.check_output([os.path.join(HOST, "host_selftest"), "--logic", str(f)]).decode()
+    r = json.loads(out[out.index("{"):])
+    assert r["verb"] == "train" and r["verbose"] == 2 and r["n"] == 200 and r["d"] == 3
+    # symmetric standardisation: one common centre / half-range for the three coordinates
+    assert abs(r["xmax"] - 1) < 1e-12 and abs(r["xmin"] + 1) < 1e-12
+    assert abs(r["ymax"] - 1) < 1e-12 and abs(r["ymin"] + 1) < 1e-12
+    assert r["roundtrip_x"] < 1e-9 and r["roundtrip_y"] < 1e-12
+    # flat parameter indexing across {ExpAns(8), Bias(1)} and the 6-significant-digit text form (Q5)
+    assert r["npars"] == 9 and r["name8"] == "Sigma_Bias" and r["p8"] == 0.2
+    assert r["p1_reloaded"] == 1.23457 and r["p3_reloaded"] == 2.0
+    stats = np.loadtxt("/tmp/gpak_logic_model_Statistics.txt", delimiter=",")
+    assert stats.shape == (4, 6)          # (d+1) x {offset, scale, min, max, mean, std}, row 0 = y
+    Xs, ys, params = synth.symmetric_standardise(Xr, yr)
+    assert np.allclose(stats[:, :2], params, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_class_surface_matches_oracle(orc, tmp_path):
+    build()
+    N, M = 700, 12
+    X, y = synth.drillholes(N)
+    Xt = synth.test_points(M)
+    write_csv(tmp_path / "tr.csv", X, y)
+    write_csv(tmp_path / "te.csv", Xt, np.zeros(M))
+    out = subprocess.check_output([os.path.join(HOST, "host_selftest"), str(tmp_path / "tr.csv"),
+                                   str(tmp_path / "te.csv")]).decode()
+    r = json.loads(out[out.index("{"):])
+    assert r["npars"] == 10
+    assert r["param_names"][:2] == ["AngleX_ExpAns", "inverseWidthx_ExpAns"] and r["param_names"][8] == "Sigma_Bias"
+    assert np.allclose(r["params"], list(E) + [0.2, 0.016], rtol=0, atol=0)
+    K = orc.gram(X, X, E, 0.2, orc.DIST_DIRECT)
+    info, alpha, L = orc.nlz_refseq(K, y, 0.016)
+    assert abs(r["K_sum"] - K.sum()) <= 1e-12 * abs(K.sum()) and r["K_00"] == E[6] ** 2 + 0.2
+    assert r["kdiag0"] == E[6] ** 2 + 0.2
+    assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+    assert r["nlz_from_grad"] == r["nlz"]
+    g = orc.grad_ref(X, y, K, L, alpha, E, 0.2, 0.016, orc.DIST_DIRECT)
+    assert np.abs(np.array(r["grad"]) - g).max() <= 1e-8 * np.abs(g).max()
+    mean, var = orc.predict(X, Xt, E, 0.2, 0.016, alpha, L, orc.DIST_DIRECT,
+                            orc.COMPAT_VARCLAMP | orc.COMPAT_SN2SKIP)
+    assert np.abs(np.array(r["mean"]) - mean).max() <= 1e-8 * np.abs(mean).max()
+    assert np.abs(np.array(r["var"]) - var).max() <= 1e-8 * np.abs(var).max()
+    info2, _, _ = orc.nlz_refseq(K, y, 0.05)
+    assert abs(r["nlz_sn2_005"] - info2.nlz) <= 1e-9 * abs(info2.nlz)
+    assert r["chol_fail_is_nan"] is True
+    assert np.allclose(r["params_reloaded"], [float(f"{v:.6g}") for v in list(E) + [0.2, 0.016]], rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_cli_train_then_test_config1(tmp_path):
+    """BASELINE.json configs[0]: N=512 3-D synthetic drill-holes, ExpAns -kn 1, train + test."""
+    build()
+    Xr, yr = synth.drillholes_raw(640)
+    write_csv(tmp_path / "train.txt", Xr[:512], yr[:512], sep="\t")
+    write_csv(tmp_path / "test.txt", Xr[512:], yr[512:], sep="\t")
+    exe = os.path.join(HOST, "gp_ss_ak")
+    model = str(tmp_path / "model")
+    env = dict(os.environ, GPAK_MAX_ITERS="15")
+    out = subprocess.check_output([exe, "-v", "1", "-np", "train", "-k", "ExpAns", "-kn", "1", "-o", "LBFGS",
+                                   str(tmp_path / "train.txt"), model], env=env, cwd=tmp_path).decode()
+    assert "There are 9 parameters to be optimized" in out
+    its = [float(line.split("-logL:")[1]) for line in out.splitlines() if line.startswith("Iteration:")]
+    assert len(its) >= 1 and all(b <= a + 1e-9 for a, b in zip(its, its[1:]))   # nlZ never increases
+    assert os.path.exists(model) and os.path.exists(model + "_Statistics.txt")
+    txt = open(model).read().splitlines()
+    assert txt[0].startswith("# GP_SS_AK Model File") and txt[1] == "Inference=Lapalce" and "KernelName=Hyb" in txt
+    mse_train = float(out.split("Mean Square Error of training:")[1].split()[0])
+    out2 = subprocess.check_output([exe, "-v", "1", "-np", "test", str(tmp_path / "test.txt"), model,
+                                    str(tmp_path / "train.txt")], cwd=tmp_path).decode()
+    mse_test = float(out2.split("Mean Square Error of testing:")[1].split()[0])
+    var_test = float(out2.split("Var MSE Test:")[1].split()[0])
+    var_train = float(out.split("Var MSE Train:")[1].split()[0])
+    assert mse_train < var_train and mse_test < var_test   # the model explains part of the variance, held-out too
+    pred = np.loadtxt(model + "_predict.txt", comments="#")
+    assert pred.shape == (128, 7) and np.all(np.diff(pred[:, 1]) >= 0)          # sorted by ascending y
+    assert os.path.exists(model + "_gnu.plt")
