@@ -55,6 +55,9 @@ struct gpak_ctx {
   double *dWork = nullptr;   // 4*Np scratch vectors
   double *dRed = nullptr;    // small reduction scratch
   int *dInfo = nullptr;      // first failing column (1-based) or 0
+  int *dQueue = nullptr;     // ring of 8-int tile queues for the persistent trailing update
+  int queue_next = 0;
+  bool persistent = false;   // the persistent trailing kernel starves the look-ahead panel of CU slots
   enum { M_NONE, M_B, M_L } mstate = M_NONE;
   bool alpha_ok = false, nlz_ok = false;
   int failed_col = 0;
@@ -124,6 +127,9 @@ int gpak_ensure_U(gpak_ctx *ctx);
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
                          int col_block0, bool lower_skip, bool trailing, bool k0_by_row = false);
+
+void gpak_launch_syrk_trailing(hipStream_t st, int mt, int K, const double *A, long lda, double *C, long ldc,
+                               int *queue);
 
 // ---- potrf.hip --------------------------------------------------------------------------
 // Factor the 128x128 block at A (ld) in place (lower), write its inverse to inv (128x128, ld 128).
