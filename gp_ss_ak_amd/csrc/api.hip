@@ -120,6 +120,7 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
   hipMalloc(&ctx->dQueue, sizeof(int) * 8 * 256);
   if (const char *pe = getenv("GPAK_PERSISTENT")) ctx->persistent = atoi(pe) != 0;
+  if (const char *pe = getenv("GPAK_FWD_IN_FACTOR")) ctx->fwd_in_factor = atoi(pe) != 0;
   const char *nb = getenv("GPAK_NB_OUTER");
   if (nb) ctx->nb_outer = atoi(nb);
   *out = ctx;
@@ -247,6 +248,8 @@ static int ensure_factor(gpak_ctx *ctx) {
   gpak_launch_fill(st, ctx->U, ctx->U, ctx->Np, ctx->Np, ctx->kp, 1.0 / ctx->sn2, 1.0, 1.0, 1, ctx->dM,
                    ctx->ld, nullptr);
   ctx->mstate = gpak_ctx::M_B;
+  ctx->z_ok = false;
+  if (ctx->fwd_in_factor) gpak_launch_scale(st, ctx->Np, ctx->dy, 1.0 / ctx->sn2, ctx->dWork);  // rhs = y/sn2
   GPAK_HIP(hipEventRecord(ctx->ev[1], st));
   rc = gpak_potrf_blocked(ctx);
   GPAK_HIP(hipEventRecord(ctx->ev[2], st));
@@ -264,6 +267,7 @@ static int ensure_factor(gpak_ctx *ctx) {
   }
   if (rc) return rc;
   ctx->mstate = gpak_ctx::M_L;
+  ctx->z_ok = ctx->fwd_in_factor;
   return GPAK_OK;
 }
 
@@ -275,8 +279,11 @@ static int ensure_alpha(gpak_ctx *ctx) {
   double *w0 = ctx->dWork, *w1 = ctx->dWork + ctx->Np;
   GPAK_HIP(hipEventRecord(ctx->ev[3], st));
   // alpha = (K + sn2 I)^-1 y = B^-1 (y / sn2)
-  gpak_launch_scale(st, ctx->Np, ctx->dy, 1.0 / ctx->sn2, w0);
-  gpak_launch_trsv_fwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
+  if (!ctx->z_ok) {
+    gpak_launch_scale(st, ctx->Np, ctx->dy, 1.0 / ctx->sn2, w0);
+    gpak_launch_trsv_fwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
+  }
+  ctx->z_ok = false;  // the back substitution consumes w1
   gpak_launch_trsv_bwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha);
   GPAK_HIP(hipEventRecord(ctx->ev[4], st));
   GPAK_HIP(hipEventSynchronize(ctx->ev[4]));

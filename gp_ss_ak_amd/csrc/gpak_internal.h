@@ -84,6 +84,8 @@ struct gpak_ctx {
   int nb_outer = 512;
   bool profile = false;
   bool lookahead = true;
+  bool fwd_in_factor = true;  // L^-1 (y/sn2) is computed block column by block column during the factorisation
+  bool z_ok = false;          // dWork[Np..2Np) holds L^-1 (y/sn2) of the current factor
 
   // timing
   gpak_phase_times times;

@@ -33,17 +33,21 @@ __device__ __forceinline__ int gpak_tix(int rt, int ct, int i, int k) {
   return ((rt * (rt + 1) / 2 + ct) << 8) + (k << 4) + i;
 }
 
-// One workgroup (4 waves) factors the 128x128 block held in LDS, 16 columns at a time:
-//   wave 0   : 16x16 diagonal block in registers (one row per lane, pivots broadcast with
-//              v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps) and its 16x16 inverse,
-//              which is parked in the unused strictly-upper half of the same tile
-//              (transposed; its diagonal goes to dd[])
-//   all waves: panel  P := P * inv(D)^T  and trailing update  C -= P P^T  on
-//              v_mfma_f64_16x16x4_f64 with operands read from LDS
-// then the 128x128 inverse by block forward substitution, one block column per wave pass:
-// a finished 16x16 accumulator tile is used directly as the B operand of the next MFMA
-// (the f64 16x16x4 D layout row=(lane>>4)+4*reg, col=lane&15 is the B-fragment layout of
-// k-step `reg`), so the inverse never goes back through LDS.
+// One workgroup (4 waves) factors the 128x128 block held in LDS, 16 columns at a time.
+//   diagonal 16x16 block (wave 0, in registers): lane i < 16 holds row i of the block, lanes
+//     16..31 hold the rows of a 16x16 IDENTITY.  Right-looking column operations (scale column
+//     j by 1/sqrt(pivot) -- v_rsq_f64 + two Newton steps, no divisions -- then column k -=
+//     column j * L[k][j], L[k][j] broadcast with v_readlane) turn the first 16 lanes into L and
+//     the identity rows into L^-T: the block's inverse costs no extra instruction.  The inverse
+//     is parked (transposed) in the unused strictly-upper half of the same LDS tile.
+//   panel  P := P * inv(D)^T  and trailing update  C -= P P^T: v_mfma_f64_16x16x4_f64 with
+//     operands read from LDS, several independent tiles in flight per wave.
+//   overlap: wave 0 updates the NEXT diagonal tile first and factors it while waves 1-3 finish
+//     the rest of the trailing update, so the serial 16x16 factorisations hide behind MFMA work.
+// Then the 128x128 inverse by block forward substitution, one block column per wave pass: a
+// finished 16x16 accumulator tile is used directly as the B operand of the next MFMA (the f64
+// 16x16x4 D layout row=(lane>>4)+4*reg, col=lane&15 is the B-fragment layout of k-step `reg`),
+// so the inverse never goes back through LDS.
 //   A      : block in global memory (column-major, ld); lower triangle is read
 //   inv    : 2 x (128x128) doubles: inv(L) then inv(L)^T, column-major ld 128
 //   col0   : global column of the block (for the not-positive-definite report)
@@ -61,105 +65,155 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
     return j > k ? T[gpak_tix(r, r, k, j)] : (j == k ? dd[r][j] : 0.0);
   };
 
-  for (int e = t; e < PB * PB; e += 256) {
-    const int r = e & (PB - 1), c = e >> 7;
-    if ((r >> 4) >= (c >> 4)) T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)] = A[r + (size_t)c * ld];
-    // strictly-upper 16x16 tiles of both inverse images are zero (the GEMMs read them)
-    else { inv[r + c * PB] = 0.0; invT[c + r * PB] = 0.0; }
+  // ---- load: 32 row pairs per thread, 16-B accesses, all loads of a batch in flight together
+#pragma unroll 8
+  for (int it = 0; it < 32; it++) {
+    const int e = t + 256 * it, r = (e & 63) * 2, c = e >> 6;
+    const double2 z = make_double2(0.0, 0.0);
+    if ((r >> 4) >= (c >> 4)) {
+      const double2 v = *reinterpret_cast<const double2 *>(A + r + (size_t)c * ld);
+      *reinterpret_cast<double2 *>(&T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)]) = v;
+      if ((r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;  // inv^T is upper
+    } else {
+      *reinterpret_cast<double2 *>(inv + r + c * PB) = z;                            // inv is lower
+    }
   }
   __syncthreads();
 
-  for (int kb = 0; kb < 8; kb++) {
-    if (w == 0) {
-      // ---- (a) diagonal block: row l15 of the block per lane (lanes 16..63 mirror 0..15)
-      double a[16], rinv[16];
+  // diagonal block kb: factor + invert (wave 0 only; see the header comment)
+  auto diag_block = [&](int kb) {
+    double a[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) a[k] = T[gpak_tix(kb, kb, l15, k)];
+    for (int k = 0; k < 16; k++) {
+      const double v = T[gpak_tix(kb, kb, l15, k)];
+      a[k] = (l4 == 1) ? (k == l15 ? 1.0 : 0.0) : v;   // lanes 16..31: identity rows
+    }
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        double d = gpak_rdlane(a[j], j);
-        if (!(d > 0.0)) {
-          if (lane == 0) atomicMin(info, col0 + 16 * kb + j + 1);
-          d = 1.0;
-        }
-        double r = __builtin_amdgcn_rsq(d);
-        double h = d * r;
-        double e = fma(-h, r, 1.0);
-        r = fma(r * 0.5, e, r);
-        h = d * r;
-        e = fma(-h, r, 1.0);
-        r = fma(r * 0.5, e, r);       // r = d^-1/2
-        double ljj = d * r;
-        ljj = fma(fma(-ljj, ljj, d) * 0.5, r, ljj);  // sqrt(d), one correction
-        rinv[j] = r;
-        a[j] = (l15 == j) ? ljj : a[j] * r;
-#pragma unroll
-        for (int k = j + 1; k < 16; k++) {
-          double lk = gpak_rdlane(a[j], k);
-          a[k] = fma(-a[j], lk, a[k]);
-        }
+    for (int j = 0; j < 16; j++) {
+      double d = gpak_rdlane(a[j], j);
+      if (!(d > 0.0)) {
+        if (lane == 0) atomicMin(info, col0 + 16 * kb + j + 1);
+        d = 1.0;
       }
-      // inverse of the 16x16 block: lane c solves L x = e_c
-      double x[16];
+      double r = __builtin_amdgcn_rsq(d);
+      double h = d * r;
+      double e = fma(-h, r, 1.0);
+      r = fma(r * 0.5, e, r);
+      h = d * r;
+      e = fma(-h, r, 1.0);
+      r = fma(r * 0.5, e, r);       // r = d^-1/2
+      double ljj = d * r;
+      ljj = fma(fma(-ljj, ljj, d) * 0.5, r, ljj);  // sqrt(d), one correction
+      a[j] = (lane == j) ? ljj : a[j] * r;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        double s = (l15 == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; k++) s = fma(-gpak_rdlane(a[k], i), x[k], s);
-        x[i] = s * rinv[i];
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          // lower part (k <= row): L ;  upper part (k > row = c): inv(D)(k, c) stored transposed
-          T[gpak_tix(kb, kb, l15, k)] = (k <= l15) ? a[k] : x[k];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-          if (i == l15) dd[kb][i] = x[i];
+      for (int k = j + 1; k < 16; k++) {
+        const double lk = gpak_rdlane(a[j], k);
+        a[k] = fma(-a[j], lk, a[k]);
       }
     }
-    __syncthreads();
+    if (l4 == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (k <= l15) T[gpak_tix(kb, kb, l15, k)] = a[k];           // L, lower part
+    } else if (l4 == 1) {
+      // identity row c = l15 became row c of L^-T: a[k] = inv(L)[k][c]; park it transposed in the
+      // strictly-upper part of the tile, its diagonal in dd[]
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        if (k > l15) T[gpak_tix(kb, kb, l15, k)] = a[k];
+        if (k == l15) dd[kb][k] = a[k];
+      }
+    }
+  };
+
+  if (w == 0) diag_block(0);
+  __syncthreads();
+
+  for (int kb = 0; kb < 7; kb++) {
     const int nt = 7 - kb;  // 16-row tiles below the diagonal block
-    // ---- (b) panel tiles: P := P * inv(D)^T  (a tile depends only on itself: no barrier inside)
-    for (int tt = w; tt < nt; tt += 4) {
-      const int rt = kb + 1 + tt;
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    // ---- panel tiles: P := P * inv(D)^T  (a tile depends only on itself: no barrier inside)
+    {
+      d4 acc[2];
+      int rt[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) { rt[u] = kb + 1 + w + 4 * u; acc[u] = (d4){0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        double pa = T[gpak_tix(rt, kb, l15, 4 * s + l4)];
-        double xb = dinv(kb, l15, 4 * s + l4);  // B[k][j] = inv(D)[j][k]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, xb, acc, 0, 0, 0);
+        const double xb = dinv(kb, l15, 4 * s + l4);  // B[k][j] = inv(D)[j][k]
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          if (rt[u] < 8) {
+            const double pa = T[gpak_tix(rt[u], kb, l15, 4 * s + l4)];
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, xb, acc[u], 0, 0, 0);
+          }
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) T[gpak_tix(rt, kb, l4 + 4 * r, l15)] = acc[r];
+      for (int u = 0; u < 2; u++)
+        if (rt[u] < 8) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) T[gpak_tix(rt[u], kb, l4 + 4 * r, l15)] = acc[u][r];
+        }
     }
     __syncthreads();
-    // ---- (c) trailing update of the lower tiles: C(ti,tj) -= P_ti * P_tj^T
+    // ---- trailing update of the lower tiles C(ti,tj) -= P_ti P_tj^T.  Tile 0 is the next
+    // diagonal tile: wave 0 updates it and goes straight on to factor it; waves 1..3 share the
+    // other tiles, four independent tiles in flight at a time.
     const int ntile = nt * (nt + 1) / 2;
-    for (int q = w; q < ntile; q += 4) {
-      int ti = 0, rem = q;
-      while (rem > ti) { rem -= ti + 1; ti++; }  // q -> (ti, tj=rem), tj <= ti
-      const int rti = kb + 1 + ti, rtj = kb + 1 + rem;
-      d4 acc;
+    auto trailing_tiles = [&](int q0, int qstep) {
+      for (int qb = q0; qb < ntile; qb += 4 * qstep) {
+        d4 acc[4];
+        int rti[4], rtj[4];
+        bool ok[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) acc[r] = T[gpak_tix(rti, rtj, l4 + 4 * r, l15)];
+        for (int u = 0; u < 4; u++) {
+          const int q = qb + u * qstep;
+          ok[u] = q < ntile;
+          int ti = 0, rem = ok[u] ? q : 0;
+          while (rem > ti) { rem -= ti + 1; ti++; }  // q -> (ti, tj=rem), tj <= ti
+          rti[u] = kb + 1 + ti; rtj[u] = kb + 1 + rem;
+          if (ok[u]) {
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        double pa = -T[gpak_tix(rti, kb, l15, 4 * s + l4)];
-        double pb = T[gpak_tix(rtj, kb, l15, 4 * s + l4)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+            for (int r = 0; r < 4; r++) acc[u][r] = T[gpak_tix(rti[u], rtj[u], l4 + 4 * r, l15)];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (ok[u]) {
+              const double pa = -T[gpak_tix(rti[u], kb, l15, 4 * s + l4)];
+              const double pb = T[gpak_tix(rtj[u], kb, l15, 4 * s + l4)];
+              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc[u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (ok[u]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) T[gpak_tix(rti[u], rtj[u], l4 + 4 * r, l15)] = acc[u][r];
+          }
       }
-#pragma unroll
-      for (int r = 0; r < 4; r++) T[gpak_tix(rti, rtj, l4 + 4 * r, l15)] = acc[r];
+    };
+    if (w == 0) {
+      trailing_tiles(0, ntile);       // just tile 0 = (kb+1, kb+1)
+      diag_block(kb + 1);
+    } else {
+      trailing_tiles(w, 3);           // tiles 1.. in steps of 3 waves
     }
     __syncthreads();
   }
 
   // L out (upper part of the block zeroed so the stored matrix is cleanly lower)
-  for (int e = t; e < PB * PB; e += 256) {
-    const int r = e & (PB - 1), c = e >> 7;
-    A[r + (size_t)c * ld] = r >= c ? T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)] : 0.0;
+#pragma unroll 8
+  for (int it = 0; it < 32; it++) {
+    const int e = t + 256 * it, r = (e & 63) * 2, c = e >> 6;
+    double2 v = make_double2(0.0, 0.0);
+    if ((r >> 4) >= (c >> 4)) {
+      v = *reinterpret_cast<const double2 *>(&T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)]);
+      if (r < c) v.x = 0.0;          // the diagonal tile's upper half holds the parked inverse
+      if (r + 1 < c) v.y = 0.0;
+    }
+    *reinterpret_cast<double2 *>(A + r + (size_t)c * ld) = v;
   }
 
   // 128x128 inverse, block column c per wave pass: X_cc = inv(D_c),
@@ -285,6 +339,10 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
     const int J = b * NB;
     const int W = (Np - J) < NB ? (Np - J) : NB;
     factor_panel(ctx, sp, J, W);
+    // forward substitution of the right-hand side y/sn2 rides along on the panel stream: block
+    // column b of L is final here, and the solve touches only the two work vectors
+    if (ctx->fwd_in_factor)
+      gpak_launch_trsv_fwd_block(sp, Np, J, W, ctx->dM, ctx->ld, ctx->dInv, ctx->dWork, ctx->dWork + Np);
     GPAK_HIP(hipEventRecord(EF[b], sp));
     const int J1 = J + W;
     if (J1 >= Np) break;

@@ -162,6 +162,7 @@ int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k) {
   hipStream_t st = ctx->stream;
   const int N = ctx->N, Np = ctx->Np;
   double *w0 = ctx->dWork, *w1 = ctx->dWork + Np, *w2 = ctx->dWork + 2 * (size_t)Np;
+  ctx->z_ok = false;
   for (int c = 0; c < k; c++) {
     GPAK_HIP(hipMemsetAsync(w0, 0, sizeof(double) * Np, st));
     GPAK_HIP(hipMemcpyAsync(w0, X_host + (size_t)c * N, sizeof(double) * N, hipMemcpyHostToDevice, st));
