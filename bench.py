@@ -147,6 +147,19 @@ def run_single(args):
                                   / PEAK_F64_MFMA_TFLOPS),
         },
     }
+    if args.grad:
+        # config 3 of BASELINE.json: what one Grad_Values() of the L-BFGS loop costs on top of ObjVal()
+        t0 = time.perf_counter()
+        for i in range(args.grad):
+            e, bias, sn2 = params_for_step(100 + i)
+            g.set_params(e, bias, sn2, mode)
+            gv = g.GradLL()
+        gwall = (time.perf_counter() - t0) / args.grad
+        tg = g.timing()
+        out["grad_step"] = {"ms_per_grad_eval": gwall * 1e3, "grad_ms": tg["grad_ms"],
+                            "algorithmic_flops": 2.0 * tim["n_padded"] ** 3 / 3.0,
+                            "tflops": 2.0 * tim["n_padded"] ** 3 / 3.0 / (tg["grad_ms"] * 1e-3) / 1e12,
+                            "g": [float(v) for v in gv]}
     if args.calibrate:
         tf, gbs = g.calibrate()
         out["roofline"]["calibrated_mfma_f64_tflops"] = tf
@@ -168,6 +181,7 @@ def main():
     ap.add_argument("--nb-outer", type=int, default=0)
     ap.add_argument("--cpu-n", type=int, default=8192, help="sample size of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--grad", type=int, default=0, help="also time this many GradLL evaluations (config 3)")
     ap.add_argument("--calibrate", action="store_true", default=True)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
