@@ -61,6 +61,24 @@ int gpak_dev_update_block(void *stream, const double *panel, long ldp, int prow0
   return status();
 }
 
+int gpak_dev_update_cyclic(void *stream, const double *panel, long ldp, int prow0, int W, double *local, long ld,
+                           int Np, int nb, int P, int rank, int lb0, int n_local_blocks, int last_width) {
+  // local tile columns [lb0*tpb, total): rows from the first included block's global start
+  const int tpb = nb / GPAK_TILE;
+  const int lt0 = lb0 * tpb;
+  const int total_tiles = (n_local_blocks - 1) * tpb + last_width / GPAK_TILE;
+  const int nt = total_tiles - lt0;
+  if (nt <= 0) return GPAK_OK;
+  const int first_global_block = lb0 * P + rank;
+  const int rt0 = first_global_block * tpb;
+  const int mt = Np / GPAK_TILE - rt0;
+  const double *Pv = panel - prow0;  // virtual base: global row g of the panel is Pv[g + k*ldp]
+  // C base: row 0 of local tile column lt0; the kernel adds the GLOBAL row tile (art) itself
+  gpak_launch_gemm_cyclic((hipStream_t)stream, mt, nt, W, Pv, ldp, local + (size_t)lt0 * GPAK_TILE * ld, ld, rt0, P,
+                          rank, tpb, lt0);
+  return status();
+}
+
 int gpak_dev_trsv_fwd_block(void *stream, const double *blk, long ld, int Np, int J, int W, const double *inv,
                             double *x, double *out) {
   const double *Lv = blk - (size_t)J * ld;

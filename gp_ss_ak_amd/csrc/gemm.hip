@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
                                                             const double *A, long lda, const double *B,
                                                             long ldb,
                                                             double beta, double *C, long ldc, int rb0,
-                                                            int cb0, int lower_skip, int mt, int nt, int k0_by_row) {
+                                                            int cb0, int lower_skip, int mt, int nt, int k0_by_row,
+                                                            int cyc_P, int cyc_rank, int cyc_tpb, int cyc_lt0) {
   // Workgroup -> tile map, XCD-aware: the dispatcher deals consecutive workgroup ids round-robin
   // over the 8 XCDs, so id b runs on XCD (b & 7) as that XCD's (b >> 3)-th workgroup.  Each XCD
   // walks 8x8 super-tiles: the 64 workgroups resident on its 32 CUs (2 per CU) cover one
@@ -58,13 +59,25 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
     if (ti >= mt || tj >= nt) return;
     if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
   }
+  // Block-column-cyclic column map (multi-GPU trailing update): the C columns are the rank's
+  // OWN block columns stored side by side; local tile column (cyc_lt0 + tj) belongs to local
+  // block lb = ./tpb, i.e. global block lb*P + rank.  A and B are then addressed by GLOBAL row
+  // tile (virtual base), and tiles above the global diagonal are skipped.
+  int gct = tj;  // tile row of the B operand
+  int art = ti;  // tile row of the A operand
+  if (cyc_P) {
+    const int lt = cyc_lt0 + tj;
+    gct = ((lt / cyc_tpb) * cyc_P + cyc_rank) * cyc_tpb + (lt % cyc_tpb);
+    art = rb0 + ti;
+    if (art < gct) return;
+  }
   __shared__ double lds[2][2][KB][LDS_LD];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = w & 1, wc = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  const double *Ag = A + (size_t)ti * TM + 2 * lane;  // per-lane source of a 16-B piece
-  const double *Bg = B + (size_t)tj * TN + 2 * lane;
+  const double *Ag = A + (size_t)art * TM + 2 * lane;  // per-lane source of a 16-B piece
+  const double *Bg = B + (size_t)gct * TN + 2 * lane;
 
   d4 acc[4][4];
 #pragma unroll
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
 
   // last stage: no more staging; the C tile (beta != 0) is fetched underneath its MFMAs
   // lane holds rows (.. + l15), columns (.. + l4 + 4*reg)
-  double *Cg = C + (size_t)ti * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + l4) * ldc;
+  double *Cg = C + (size_t)art * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + l4) * ldc;
   const int lbuf = (nstage - 1) & 1;
   if (beta == 0.0) {
     GPAK_COMPUTE(lbuf)
@@ -151,6 +164,19 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
   }
 #undef GPAK_STAGE
 #undef GPAK_COMPUTE
+}
+
+// Trailing update of ALL block columns a rank owns beyond local tile column lt0, in one launch:
+// C_local[rows >= rt0*128, local tile columns lt0..] -= Pv[rows] * Pv[global column rows]^T where
+// Pv is the panel addressed by global row (virtual base).  See the cyc_* comment in the kernel.
+void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double *Pv, long ldp, double *Clocal,
+                             long ldc, int rt0, int P, int rank, int tpb, int lt0) {
+  if (mt <= 0 || nt <= 0) return;
+  const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
+  const long nsuper = (long)SR * SC;
+  dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
+  hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, -1.0, Pv, ldp, Pv, ldp, 1.0, Clocal, ldc, rt0, 0,
+                     0, mt, nt, 0, P, rank, tpb, lt0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -297,10 +323,10 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   if (trailing)
     hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
   else
     hipLaunchKernelGGL(gpak_gemm_nt_f64<false>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -48,7 +48,7 @@ class HipEngine:
         self.device = torch.device("cuda", device_index)
         self.lib = _lib.load()
         for name in ("gpak_dev_transform", "gpak_dev_fill_b", "gpak_dev_factor_panel", "gpak_dev_update_block",
-                     "gpak_dev_trsv_fwd_block", "gpak_dev_coldot", "gpak_dev_trsv_bwd_block",
+                     "gpak_dev_update_cyclic", "gpak_dev_trsv_fwd_block", "gpak_dev_coldot", "gpak_dev_trsv_bwd_block",
                      "gpak_dev_logdiag_block", "gpak_dev_kmatvec", "gpak_dev_nlz_terms"):
             if not hasattr(self.lib, name):
                 raise RuntimeError(f"libgpak_hip.so lacks {name}")
@@ -114,6 +114,11 @@ class HipEngine:
         self._chk(self.lib.gpak_dev_update_block(self._st(), self._p(panel), C.c_long(ldp), prow0, W, self._p(blk),
                                                  C.c_long(ld), Np, Jc, Wc), "gpak_dev_update_block")
 
+    def update_cyclic(self, panel, ldp, prow0, W, local, ld, Np, nb, P, rank, lb0, n_local, last_width):
+        self._chk(self.lib.gpak_dev_update_cyclic(self._st(), self._p(panel), C.c_long(ldp), prow0, W,
+                                                  self._p(local), C.c_long(ld), Np, nb, P, rank, lb0, n_local,
+                                                  last_width), "gpak_dev_update_cyclic")
+
     def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out):
         self._chk(self.lib.gpak_dev_trsv_fwd_block(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(inv),
                                                    self._p(x), self._p(out)), "gpak_dev_trsv_fwd_block")
@@ -169,7 +174,11 @@ class DistGP:
         self.y = engine.from_numpy(yp)
         self.xsum = X.sum(axis=0)
         self.u = engine.empty(4 * self.cap)
-        self.blk = {b: engine.empty(self.ld * self.width(b)) for b in self.owned}
+        # the rank's block columns side by side in ONE array (nb columns each, leading dimension ld), so
+        # that the trailing update of all of them is a single launch (gpak_dev_update_cyclic)
+        self.local = engine.empty(max(1, len(self.owned)) * self.nb * self.ld)
+        self.blk = {b: self.local[i * self.nb * self.ld: i * self.nb * self.ld + self.width(b) * self.ld]
+                    for i, b in enumerate(self.owned)}
         self.inv = {b: engine.empty(self.width(b) // TILE * 2 * TILE * TILE) for b in self.owned}
         self.info = engine.zeros(4, dtype=torch.int32)
         self.scratch = engine.empty(64 * self.cap)
@@ -261,10 +270,10 @@ class DistGP:
                 finally:
                     if streams:
                         ctx.__exit__(None, None, None)
-            for c in self.owned:
-                if c > nxt:
-                    self.eng.update_block(panel, rows, J + W, W, self.blk[c], self.ld, self.Np, self.start(c),
-                                          self.width(c))
+            lb0 = next((i for i, c in enumerate(self.owned) if c > nxt), None)
+            if lb0 is not None:
+                self.eng.update_cyclic(panel, rows, J + W, W, self.local, self.ld, self.Np, self.nb, self.P,
+                                       self.rank, lb0, len(self.owned), self.width(self.owned[-1]))
             if handle is not None:
                 handle.wait()
             if streams and nxt < self.nJ:

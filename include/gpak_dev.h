@@ -42,6 +42,12 @@ int gpak_dev_factor_panel(void *stream, double *blk, long ld, int Np, int J, int
 int gpak_dev_update_block(void *stream, const double *panel, long ldp, int prow0, int W, double *blk, long ld,
                           int Np, int Jc, int Wc);
 
+/* The same update for ALL block columns the rank owns from local block lb0 on, in ONE launch.
+ * `local` is the rank's storage: its n_local_blocks block columns side by side (each nb columns,
+ * leading dimension ld, the last one last_width wide); local block lb is global block lb*P+rank. */
+int gpak_dev_update_cyclic(void *stream, const double *panel, long ldp, int prow0, int W, double *local, long ld,
+                           int Np, int nb, int P, int rank, int lb0, int n_local_blocks, int last_width);
+
 /* Forward substitution step for block column [J, J+W):  out[J..J+W) = L_bb^-1 x[J..J+W) and
  * x[r] -= L[r, J..J+W) out  for every r >= J+W.  x, out have Np entries. */
 int gpak_dev_trsv_fwd_block(void *stream, const double *blk, long ld, int Np, int J, int W, const double *inv,

@@ -83,6 +83,13 @@ class NumpyEngine:
         a = P[Jc - prow0:Np - prow0, :]
         C[Jc:Np, :] -= a @ a[:Wc, :].T
 
+    def update_cyclic(self, panel, ldp, prow0, W, local, ld, Np, nb, P, rank, lb0, n_local, last_width):
+        for lb in range(lb0, n_local):
+            Wc = last_width if lb == n_local - 1 else nb
+            Jc = (lb * P + rank) * nb
+            blk = local[lb * nb * ld: lb * nb * ld + Wc * ld]
+            self.update_block(panel, ldp, prow0, W, blk, ld, Np, Jc, Wc)
+
     def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out):
         M = blk.numpy().reshape(W, ld).T
         iv = inv.numpy().reshape(W // TILE, 2, TILE, TILE)
