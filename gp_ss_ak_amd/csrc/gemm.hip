@@ -333,18 +333,28 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
 // Calibration microbenchmarks: back-to-back fp64 MFMA issue and a
 // streaming 16-B store, so roofline fractions can be quoted against measured ceilings too.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gpak_calib_mfma_f64(double *out, int iters) {
-  d4 acc[8];
-  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+__global__ __launch_bounds__(256, 2) void gpak_calib_mfma_f64(double *out, int iters) {
+  // the register-level shape of the GEMM's inner step: 4 A x 4 B fragments -> 16 accumulators
+  d4 acc[4][4];
+  double a[4], b[4];
 #pragma unroll
-  for (int i = 0; i < 8; i++) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < 4; i++) {
+    a[i] = 1.0 + (threadIdx.x + 7 * i) * 1e-9;
+    b[i] = 1.0 - (threadIdx.x + 3 * i) * 1e-9;
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0);
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
   if (s == 12345.678) out[0] = s;  // keep the chain live
 }
 
@@ -358,15 +368,15 @@ int gpak_calibrate_impl(gpak_ctx *ctx, double *scratch, size_t scratch_bytes, do
   hipEvent_t e0, e1;
   GPAK_HIP(hipEventCreate(&e0));
   GPAK_HIP(hipEventCreate(&e1));
-  const int iters = 4096, blocks = 256 * 8;
-  hipLaunchKernelGGL(gpak_calib_mfma_f64, dim3(blocks), dim3(256), 0, ctx->stream, scratch, 64);
+  const int iters = 32768, blocks = 256 * 2;  // 2 workgroups per CU like the GEMM; ~30 ms so that the clock has settled
+  hipLaunchKernelGGL(gpak_calib_mfma_f64, dim3(blocks), dim3(256), 0, ctx->stream, scratch, iters / 2);
   GPAK_HIP(hipEventRecord(e0, ctx->stream));
   hipLaunchKernelGGL(gpak_calib_mfma_f64, dim3(blocks), dim3(256), 0, ctx->stream, scratch, iters);
   GPAK_HIP(hipEventRecord(e1, ctx->stream));
   GPAK_HIP(hipEventSynchronize(e1));
   float ms = 0;
   GPAK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
+  double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * (2.0 * 16 * 16 * 4);
   *tflops = flops / (ms * 1e-3) / 1e12;
   size_t n2 = scratch_bytes / 16;
   hipLaunchKernelGGL(gpak_calib_store, dim3(2048), dim3(256), 0, ctx->stream, (double2 *)scratch, n2);
