@@ -177,9 +177,10 @@ GP_utils *readGpFromFile(const std::string &modelFileName, int verbosity) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// optimiser (see the note in gp_utils.hpp: role of Opt_pars.cpp:179-332, not its trajectory)
+// A plain projected L-BFGS with backtracking (NOT the reference's algorithm; opt_algs.cpp holds
+// the restatement of Opt_pars.cpp).  Kept as an alternative driver: GPAK_OPT=simple.
 // ---------------------------------------------------------------------------------------------
-void Opt_Algs::LBFGSOptimise() {
+void Opt_Algs::SimpleLBFGSOptimise() {
   const unsigned n = getNumPars();
   const double lb = 1e-4, ub = 6.0;  // Opt_pars.cpp:184-188
   const unsigned mem = 6;

@@ -3,6 +3,7 @@
 // GP_utils (GP_Utils.h:23-389).  Same member names and call sequence; every O(N^2)/O(N^3)
 // member forwards to the C-ABI (include/gpak.h) instead of Armadillo.
 #pragma once
+#include <cstdlib>
 #include <limits>
 #include <string>
 
@@ -56,13 +57,17 @@ class Opt_Algs {
   std::string getDefaultOptimiserStr() const { return defaultOptimiser == SCG ? "SCG" : defaultOptimiser == BFGS ? "BFGS" : "LBFGS"; }
   void setMaxIters(unsigned int v) { maxIters = v; }
   unsigned int getMaxIters() const { return maxIters; }
-  // Bound-constrained limited-memory quasi-Newton loop in the role of Opt_pars.cpp:179-332:
-  // box [1e-4, 6] on every parameter (:184-188), memory 6 (:190), a step is accepted only when
-  // the objective decreases (:268), progress lines "Iteration: k -logL: v" (:281-282, :327-328).
-  // NOT a line-by-line restatement of the reference's Cauchy-point / Potra-Shi search
-  // (SURVEY.md 8(f-2), next row): the parameter trajectory differs from the reference's.
+  // Opt_pars.cpp:179-332 with cauchy_point (:11-105), Primal_Conjugate_grad (:108-174) and
+  // Efficient_line_search (:543-974), restated as written in opt_algs.cpp: box [1e-4, 6] on every
+  // parameter, memory 6, progress lines "Iteration: k -logL: v".
   void LBFGSOptimise();
-  void Optimise() { LBFGSOptimise(); }
+  // plain projected L-BFGS with backtracking (not the reference's trajectory); GPAK_OPT=simple
+  void SimpleLBFGSOptimise();
+  void Optimise() {
+    const char *e = getenv("GPAK_OPT");
+    if (e && std::string(e) == "simple") SimpleLBFGSOptimise();
+    else LBFGSOptimise();
+  }
   unsigned int numFuncEval = 0;
 
  private:

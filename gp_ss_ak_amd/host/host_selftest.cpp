@@ -55,8 +55,50 @@ static int logic_only(const char *train_csv) {
   return 0;
 }
 
+// The optimiser on an analytic objective (no device): f(x) = sum_i w_i (x_i - c_i)^2 +
+// 0.05 sum_i x_i x_{i+1} + 0.01 sum_i x_i^4, some minimisers outside the box [1e-4, 6].
+class QuadModel : public Opt_Algs {
+ public:
+  mutable std::vector<double> x{1.5, 0.9, 2.5, 0.3, 4.0, 1.1};
+  std::vector<double> w{1.0, 3.0, 0.5, 2.0, 0.25, 1.5}, c{2.0, 7.0, -1.0, 0.5, 3.0, 5.5};
+  explicit QuadModel(int variant) {
+    if (variant == 1) { x = {0.5, 0.5, 0.5, 0.5, 0.5, 0.5}; w = {0.2, 0.4, 0.6, 0.8, 1.0, 1.2}; c = {1.0, 2.0, 3.0, 4.0, 5.0, 5.9}; }
+    if (variant == 2) { x = {5.5, 0.01, 3.0, 3.0, 0.2, 2.2}; w = {2.0, 0.1, 1.0, 1.0, 3.0, 0.7}; c = {8.0, -2.0, 3.1, 2.9, 0.1, 2.0}; }
+  }
+  unsigned int getNumPars() const override { return 6; }
+  void get_GP_Pars(mat &p) const override { for (int i = 0; i < 6; i++) p(i) = x[i]; }
+  void set_GP_Pars(mat &p) const override { for (int i = 0; i < 6; i++) x[i] = p(i); }
+  double eval(double *g) const {
+    double f = 0;
+    for (int i = 0; i < 6; i++) {
+      f += w[i] * (x[i] - c[i]) * (x[i] - c[i]) + 0.01 * x[i] * x[i] * x[i] * x[i];
+      if (g) g[i] = 2 * w[i] * (x[i] - c[i]) + 0.04 * x[i] * x[i] * x[i];
+    }
+    for (int i = 0; i < 5; i++) {
+      f += 0.05 * x[i] * x[i + 1];
+      if (g) { g[i] += 0.05 * x[i + 1]; g[i + 1] += 0.05 * x[i]; }
+    }
+    return f;
+  }
+  double Grad_Values(mat &g) const override { double gg[6]; double f = eval(gg); for (int i = 0; i < 6; i++) g(i) = gg[i]; return f; }
+  double ObjVal() const override { return eval(nullptr); }
+};
+
+static int opt_only(int maxit, int variant) {
+  QuadModel m(variant);
+  m.setVerbose(1);
+  m.setMaxIters(maxit);
+  std::cout.precision(17);
+  m.LBFGSOptimise();
+  printf("FINAL");
+  for (double v : m.x) printf(" %.17g", v);
+  printf("\nNFEV %u\n", m.numFuncEval);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc >= 3 && std::string(argv[1]) == "--logic") return logic_only(argv[2]);
+  if (argc >= 3 && std::string(argv[1]) == "--opt") return opt_only(atoi(argv[2]), argc >= 4 ? atoi(argv[3]) : 0);
   if (argc < 3) { fprintf(stderr, "usage: host_selftest train.csv test.csv\n"); return 2; }
   char *cargv[] = {argv[0], nullptr};
   Control io(1, cargv);

@@ -52,6 +52,49 @@ def test_host_logic_without_a_gpu(tmp_path):
     assert np.allclose(stats[:, :2], params, rtol=1e-12)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_lbfgs_restatement_matches_independent_numpy_restatement(variant):
+    """Opt_Algs::LBFGSOptimise (host/opt_algs.cpp) vs tests/lbfgs_ref.py, both written from
+    Opt_pars.cpp:11-332, 543-974.  The algorithm is a chain of exact comparisons, so the two are
+    made to round identically and compared BIT FOR BIT: objective after every iteration, final
+    point, number of function evaluations."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lbfgs_ref
+    build()
+    cfg = {0: ([1.5, 0.9, 2.5, 0.3, 4.0, 1.1], [1.0, 3.0, 0.5, 2.0, 0.25, 1.5], [2.0, 7.0, -1.0, 0.5, 3.0, 5.5]),
+           1: ([0.5] * 6, [0.2, 0.4, 0.6, 0.8, 1.0, 1.2], [1.0, 2.0, 3.0, 4.0, 5.0, 5.9]),
+           2: ([5.5, 0.01, 3.0, 3.0, 0.2, 2.2], [2.0, 0.1, 1.0, 1.0, 3.0, 0.7], [8.0, -2.0, 3.1, 2.9, 0.1, 2.0])}
+    x0, w, c = cfg[variant]
+
+    def fg(x):
+        x = [float(v) for v in x]
+        f, g = 0.0, [0.0] * 6
+        for i in range(6):
+            f += w[i] * (x[i] - c[i]) * (x[i] - c[i]) + 0.01 * x[i] * x[i] * x[i] * x[i]
+            g[i] = 2 * w[i] * (x[i] - c[i]) + 0.04 * x[i] * x[i] * x[i]
+        for i in range(5):
+            f += 0.05 * x[i] * x[i + 1]
+            g[i] += 0.05 * x[i + 1]
+            g[i + 1] += 0.05 * x[i]
+        return f, np.array(g)
+
+    maxit = 15
+    xr, hist, nfev = lbfgs_ref.lbfgs_optimise(fg, x0, maxit)
+    out = subprocess.check_output([os.path.join(HOST, "host_selftest"), "--opt", str(maxit), str(variant)]).decode()
+    lines = out.splitlines()
+    ch = [float(l.split("-logL:")[1]) for l in lines if l.startswith("Iteration")]
+    xf = [float(v) for v in [l for l in lines if l.startswith("FINAL")][0].split()[1:]]
+    nf = int([l for l in lines if l.startswith("NFEV")][0].split()[1])
+    # the reference prints no line for the last iteration when it ends through `iter >= Maxit`
+    assert len(ch) in (maxit, maxit - 1)
+    assert all(float(a) == b for a, b in zip(hist, ch))
+    assert [float(v) for v in xr] == xf
+    assert nf == nfev
+    assert all(b <= a for a, b in zip(ch, ch[1:]))       # the kept objective never increases
+    assert all(1e-4 <= v <= 6.0 for v in xf)             # Q8: box [1e-4, 6] on every parameter
+
+
 @pytest.mark.gpu
 def test_class_surface_matches_oracle(orc, tmp_path):
     build()
