@@ -132,6 +132,8 @@ def test_cli_train_then_test_config1(tmp_path):
     """BASELINE.json configs[0]: N=512 3-D synthetic drill-holes, ExpAns -kn 1, train + test."""
     build()
     Xr, yr = synth.drillholes_raw(640)
+    perm = np.random.default_rng(5).permutation(640)     # held-out samples interleaved with the training holes
+    Xr, yr = Xr[perm], yr[perm]
     write_csv(tmp_path / "train.txt", Xr[:512], yr[:512], sep="\t")
     write_csv(tmp_path / "test.txt", Xr[512:], yr[512:], sep="\t")
     exe = os.path.join(HOST, "gp_ss_ak")
