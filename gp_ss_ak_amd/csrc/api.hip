@@ -77,6 +77,10 @@ static void release_train(gpak_ctx *ctx) {
   gpak_grad_release(ctx);
   ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dAlpha = ctx->dWork = ctx->dF = nullptr;
   free_points(ctx->U);
+  if (ctx->dLf) hipFree(ctx->dLf);
+  if (ctx->dInvf) hipFree(ctx->dInvf);
+  ctx->dLf = ctx->dInvf = nullptr;
+  ctx->lf_ok = false;
   ctx->N = ctx->Np = 0;
   ctx->mstate = gpak_ctx::M_NONE;
   ctx->alpha_ok = ctx->nlz_ok = false;
@@ -97,7 +101,7 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
     return GPAK_EHIP;
   }
   if (device < 0 || device >= count) { g_global_err = "device ordinal out of range"; return GPAK_EINVAL; }
-  if (precision != GPAK_F64) { g_global_err = "only GPAK_F64 is built in this round"; return GPAK_ENOTIMPL; }
+  if (precision != GPAK_F64 && precision != GPAK_F32) { g_global_err = "precision must be GPAK_F64 or GPAK_F32"; return GPAK_EINVAL; }
   if ((e = hipSetDevice(device)) != hipSuccess) { g_global_err = hipGetErrorString(e); return GPAK_EHIP; }
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_global_err = hipGetErrorString(e); return GPAK_EHIP; }
@@ -249,6 +253,7 @@ static int ensure_factor(gpak_ctx *ctx) {
                    ctx->ld, nullptr);
   ctx->mstate = gpak_ctx::M_B;
   ctx->z_ok = false;
+  ctx->lf_ok = false;
   if (ctx->fwd_in_factor) gpak_launch_scale(st, ctx->Np, ctx->dy, 1.0 / ctx->sn2, ctx->dWork);  // rhs = y/sn2
   GPAK_HIP(hipEventRecord(ctx->ev[1], st));
   rc = gpak_potrf_blocked(ctx);

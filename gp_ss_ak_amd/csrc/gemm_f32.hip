@@ -1,0 +1,192 @@
+// gemm_f32.hip -- fp32 sibling of gemm.hip for the prediction path (BASELINE.json configs[4]:
+// fp32, M = 1e6 test points): C = beta*C + alpha * A * B^T on v_mfma_f32_16x16x4_f32
+// (157 TFLOP/s dense on MI355X = twice the fp64 matrix rate).
+//
+// Same geometry as the fp64 kernel: 128x128 tile, 4 waves (2x2), each 64x64 = 4x4 MFMA tiles,
+// LDS-DMA staging of [k][row] images, two buffers, one barrier per stage.  Differences:
+//   * a stage is 32 k deep (16 KiB per operand, like 16 k of fp64); one 16-B LDS-DMA instruction
+//     covers TWO k-rows (2 x 128 floats), so the image is unpadded (row = 512 B) -- the two
+//     k-planes a 32-lane group reads then share banks (2-way), which the fp32 MFMA rate hides;
+//   * the f32 16x16x4 result layout is the standard one (col = lane&15, row = 4*(lane>>4)+reg);
+//     with the operand roles swapped as in gemm.hip a lane holds row (lane&15), columns
+//     4*(lane>>4) + reg of its 16x16 tile.
+#include "gpak_internal.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define TM 128
+#define TN 128
+#define KB32 32
+
+__global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f32(int K, float alpha, const float *A, long lda,
+                                                            const float *B, long ldb, float beta, float *C,
+                                                            long ldc, int mt, int nt) {
+  int ti, tj;
+  {
+    const int b = blockIdx.x, q = b >> 3;
+    const int slot = q & 63;
+    const int ssel = (q >> 6) * 8 + (b & 7);
+    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
+    const int sj = ssel / SR, si = ssel - sj * SR;
+    if (sj >= SC) return;
+    ti = si * 8 + (slot & 7);
+    tj = sj * 8 + (slot >> 3);
+    if (ti >= mt || tj >= nt) return;
+  }
+  __shared__ float lds[2][2][KB32][TM];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = w & 1, wc = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // LDS-DMA piece of a wave instruction: lanes 0..31 -> k-row 2p, lanes 32..63 -> k-row 2p+1
+  const int lrow = (lane & 31) * 4, lk = lane >> 5;
+  const float *Ag = A + (size_t)ti * TM + lrow + (size_t)lk * lda;
+  const float *Bg = B + (size_t)tj * TN + lrow + (size_t)lk * ldb;
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int nstage = K / KB32;
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  // wave w stages k-row pairs w, w+4, w+8, w+12 (rows 2p, 2p+1) of both operands
+#define GPAK_STAGE32(buf_, kbase_)                                                                   \
+  _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                    \
+    const int p_ = w + 4 * s;                                                                        \
+    const size_t k_ = (size_t)(kbase_) + 2 * p_;                                                     \
+    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + k_ * lda), (lptr_t)&lds[buf_][0][2 * p_][0], 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + k_ * ldb), (lptr_t)&lds[buf_][1][2 * p_][0], 16, 0, 0); \
+  }
+#define GPAK_COMPUTE32(buf_)                                                                         \
+  _Pragma("unroll") for (int kk = 0; kk < KB32 / 4; kk++) {                                          \
+    float a[4], b[4];                                                                                \
+    _Pragma("unroll") for (int mi = 0; mi < 4; mi++) a[mi] = lds[buf_][0][kk * 4 + l4][wr * 64 + mi * 16 + l15]; \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ni++) b[ni] = lds[buf_][1][kk * 4 + l4][wc * 64 + ni * 16 + l15]; \
+    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                 \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                             \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni], a[mi], acc[mi][ni], 0, 0, 0);  \
+  }
+
+  GPAK_STAGE32(0, 0)
+  __syncthreads();
+  for (int st = 0; st + 1 < nstage; st++) {
+    const int buf = st & 1;
+    GPAK_STAGE32(buf ^ 1, (size_t)(st + 1) * KB32)
+    GPAK_COMPUTE32(buf)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  const int lbuf = (nstage - 1) & 1;
+  GPAK_COMPUTE32(lbuf)
+  // lane holds row (.. + l15), columns (.. + 4*l4 + reg)
+  float *Cg = C + (size_t)ti * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + 4 * l4) * ldc;
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float *p = Cg + mi * 16 + (size_t)(ni * 16 + r) * ldc;
+        const float v = alpha * acc[mi][ni][r];
+        *p = (beta == 0.f) ? v : fmaf(beta, *p, v);
+      }
+#undef GPAK_STAGE32
+#undef GPAK_COMPUTE32
+}
+
+void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha, const float *A, long lda,
+                             const float *B, long ldb, float beta, float *C, long ldc) {
+  if (mt <= 0 || nt <= 0) return;
+  const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
+  const long nsuper = (long)SR * SC;
+  dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
+  hipLaunchKernelGGL(gpak_gemm_nt_f32, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+}
+
+// ---- fp32 images of the fp64 factor ---------------------------------------------------------
+__global__ void gpak_lower_to_f32(const double *__restrict__ L, long ld, int Np, float *__restrict__ out, long ldo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)Np * Np;
+  if (i >= tot) return;
+  const size_t c = i / Np, r = i - c * Np;
+  out[r + c * ldo] = r >= c ? (float)L[r + c * ld] : 0.f;
+}
+__global__ void gpak_vec_to_f32(const double *__restrict__ in, size_t n, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+void gpak_launch_lower_to_f32(hipStream_t st, const double *L, long ld, int Np, float *out, long ldo) {
+  const size_t tot = (size_t)Np * Np;
+  hipLaunchKernelGGL(gpak_lower_to_f32, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, L, ld, Np, out, ldo);
+}
+void gpak_launch_vec_to_f32(hipStream_t st, const double *in, size_t n, float *out) {
+  hipLaunchKernelGGL(gpak_vec_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, out);
+}
+
+// ---- fp32 cross-kernel fill (test-major batch) and row sums of squares ------------------------
+// distance in fp64 from the fp64 coordinates (three subtractions), profile sqrt/exp in fp32
+__global__ __launch_bounds__(256) void gpak_fill_f32(const double *__restrict__ pu0, const double *__restrict__ pu1,
+                                                      const double *__restrict__ pu2, int nP,
+                                                      const double *__restrict__ qu0, const double *__restrict__ qu1,
+                                                      const double *__restrict__ qu2, int nQ, float var2, float bias,
+                                                      float *__restrict__ C, long ld) {
+  const int row0 = blockIdx.x * 128, col0 = blockIdx.y * 64;
+  __shared__ double q[3][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < 64) {
+    const int j = col0 + t;
+    const bool ok = j < nQ;
+    q[0][t] = ok ? qu0[j] : 0.0; q[1][t] = ok ? qu1[j] : 0.0; q[2][t] = ok ? qu2[j] : 0.0;
+  }
+  const int r = row0 + 2 * lane;
+  const double2 a0 = *reinterpret_cast<const double2 *>(pu0 + r);
+  const double2 a1 = *reinterpret_cast<const double2 *>(pu1 + r);
+  const double2 a2 = *reinterpret_cast<const double2 *>(pu2 + r);
+  __syncthreads();
+#pragma unroll 4
+  for (int c = 0; c < 16; c++) {
+    const int jl = w + 4 * c, j = col0 + jl;
+    const double b0 = q[0][jl], b1 = q[1][jl], b2 = q[2][jl];
+    double dx = a0.x - b0, dy = a1.x - b1, dz = a2.x - b2;
+    const float d0 = (float)(dx * dx + dy * dy + dz * dz);
+    dx = a0.y - b0; dy = a1.y - b1; dz = a2.y - b2;
+    const float d1 = (float)(dx * dx + dy * dy + dz * dz);
+    float k0 = var2 * __expf(-sqrtf(d0)) + bias, k1 = var2 * __expf(-sqrtf(d1)) + bias;
+    const bool cj = j < nQ;
+    if (!(cj && r < nP)) k0 = 0.f;
+    if (!(cj && r + 1 < nP)) k1 = 0.f;
+    *reinterpret_cast<float2 *>(C + r + (size_t)j * ld) = make_float2(k0, k1);
+  }
+}
+void gpak_launch_fill_f32(hipStream_t st, const DevPoints &P, const DevPoints &Q, int rows_p, int cols_p,
+                          const KernParams &kp, float *C, long ld) {
+  dim3 grid(rows_p / 128, cols_p / 64);
+  hipLaunchKernelGGL(gpak_fill_f32, grid, dim3(256), 0, st, P.u0, P.u1, P.u2, P.n, Q.u0, Q.u1, Q.u2, Q.n,
+                     (float)kp.var2, (float)kp.bias, C, ld);
+}
+
+__global__ __launch_bounds__(256) void gpak_rowsumsq_part_f32(const float *__restrict__ V, long ldv, int rows, int cols,
+                                                               int cols_per_split, double *__restrict__ part,
+                                                               int part_ld) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows) return;
+  const int c0 = blockIdx.y * cols_per_split;
+  const int c1 = min(cols, c0 + cols_per_split);
+  double s = 0.0;
+  float blk = 0.f;
+  int n = 0;
+  for (int c = c0; c < c1; c++) {
+    const float a = V[t + (size_t)c * ldv];
+    blk = fmaf(a, a, blk);
+    if (++n == 64) { s += blk; blk = 0.f; n = 0; }  // fp32 partials of 64 terms, fp64 across them
+  }
+  part[(size_t)blockIdx.y * part_ld + t] = s + blk;
+}
+void gpak_launch_rowsumsq_f32(hipStream_t st, const float *V, long ldv, int rows, int cols, int splits,
+                              double *part, int part_ld) {
+  int cps = (cols + splits - 1) / splits;
+  hipLaunchKernelGGL(gpak_rowsumsq_part_f32, dim3((rows + 255) / 256, splits), dim3(256), 0, st, V, ldv, rows, cols,
+                     cps, part, part_ld);
+}

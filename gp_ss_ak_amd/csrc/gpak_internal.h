@@ -71,6 +71,9 @@ struct gpak_ctx {
   double *dPart = nullptr;   // 64 x pred_cap partial sums
   int pred_cap = 0;
   size_t wt_elems = 0;
+  // fp32 prediction (ctx created with GPAK_F32): fp32 images of L and of the inverse blocks
+  float *dLf = nullptr, *dInvf = nullptr;
+  bool lf_ok = false;
 
   // gradient buffers (allocated on the first gpak_grad)
   double *dG = nullptr;      // Np x ld: L^-T (upper triangular)
@@ -134,6 +137,16 @@ void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double
                              long ldc, int rt0, int P, int rank, int tpb, int lt0);
 void gpak_launch_syrk_trailing(hipStream_t st, int mt, int K, const double *A, long lda, double *C, long ldc,
                                int *queue);
+
+// ---- gemm_f32.hip (fp32 prediction path) ---------------------------------------------------
+void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha, const float *A, long lda,
+                             const float *B, long ldb, float beta, float *C, long ldc);
+void gpak_launch_lower_to_f32(hipStream_t st, const double *L, long ld, int Np, float *out, long ldo);
+void gpak_launch_vec_to_f32(hipStream_t st, const double *in, size_t n, float *out);
+void gpak_launch_fill_f32(hipStream_t st, const DevPoints &P, const DevPoints &Q, int rows_p, int cols_p,
+                          const KernParams &kp, float *C, long ld);
+void gpak_launch_rowsumsq_f32(hipStream_t st, const float *V, long ldv, int rows, int cols, int splits,
+                              double *part, int part_ld);
 
 // ---- potrf.hip --------------------------------------------------------------------------
 // Factor the 128x128 block at A (ld) in place (lower), write its inverse to inv (128x128, ld 128).

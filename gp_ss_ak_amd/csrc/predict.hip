@@ -41,6 +41,10 @@ void gpak_predict_release(gpak_ctx *ctx) {
   if (ctx->dWt) hipFree(ctx->dWt);
   if (ctx->dPv) hipFree(ctx->dPv);
   if (ctx->dPart) hipFree(ctx->dPart);
+  if (ctx->dLf) hipFree(ctx->dLf);
+  if (ctx->dInvf) hipFree(ctx->dInvf);
+  ctx->dLf = ctx->dInvf = nullptr;
+  ctx->lf_ok = false;
   ctx->dXte = ctx->dWt = ctx->dPv = ctx->dPart = nullptr;
   ctx->pred_cap = 0; ctx->wt_elems = 0;
 }
@@ -94,6 +98,40 @@ static void forward_subst_batch(gpak_ctx *ctx, double *Wt, long ldw, int mbp) {
   }
 }
 
+// fp32 images of the factor for a GPAK_F32 context (rebuilt when the factor changes)
+static int ensure_f32_factor(gpak_ctx *ctx) {
+  if (ctx->lf_ok) return GPAK_OK;
+  const int Np = ctx->Np, T = Np / PB;
+  if (!ctx->dLf) {
+    if (hipMalloc(&ctx->dLf, sizeof(float) * (size_t)Np * Np) != hipSuccess ||
+        hipMalloc(&ctx->dInvf, sizeof(float) * (size_t)T * 2 * PB * PB) != hipSuccess) {
+      ctx->err = "device allocation failed for the fp32 factor image";
+      return GPAK_ENOMEM;
+    }
+  }
+  gpak_launch_lower_to_f32(ctx->stream, ctx->dM, ctx->ld, Np, ctx->dLf, Np);
+  gpak_launch_vec_to_f32(ctx->stream, ctx->dInv, (size_t)T * 2 * PB * PB, ctx->dInvf);
+  ctx->lf_ok = true;
+  return GPAK_OK;
+}
+
+// the same blocked forward substitution in fp32 (v_mfma_f32_16x16x4_f32)
+static void forward_subst_batch_f32(gpak_ctx *ctx, float *Wt, long ldw, int mbp) {
+  const int Np = ctx->Np, T = Np / PB;
+  hipStream_t st = ctx->stream;
+  const int mt = mbp / PB;
+  for (int jb = 0; jb < T; jb++) {
+    const size_t j0 = (size_t)jb * PB;
+    const float *inv = ctx->dInvf + (size_t)jb * 2 * PB * PB;
+    float *Wj = Wt + j0 * ldw;
+    gpak_launch_gemm_nt_f32(st, mt, 1, PB, 1.f, Wj, ldw, inv, PB, 0.f, Wj, ldw);
+    const int nrest = T - jb - 1;
+    if (nrest > 0)
+      gpak_launch_gemm_nt_f32(st, mt, nrest, PB, -1.f, Wj, ldw, ctx->dLf + (j0 + PB) + j0 * Np, Np, 1.f,
+                              Wt + (j0 + PB) * ldw, ldw);
+  }
+}
+
 int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var) {
   GPAK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -106,6 +144,8 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   const int cap = (int)std::min<long>(Mp, batch);
   int rc = ensure_predict_bufs(ctx, cap, var != nullptr);
   if (rc) return rc;
+  const bool f32 = ctx->precision == GPAK_F32;
+  if (f32 && var && (rc = ensure_f32_factor(ctx))) return rc;
   hipEvent_t e0 = ctx->ev[5], e1 = ctx->ev[6];
   GPAK_HIP(hipEventRecord(e0, st));
 
@@ -134,12 +174,21 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
     GPAK_HIP(hipMemcpyAsync(mean + b0, dMean, sizeof(double) * mb, hipMemcpyDeviceToHost, st));
     if (var) {
       const long ldw = cap;
-      gpak_launch_fill(st, ctx->Tq, ctx->Upred, mbp, Np, kp, 1.0, 0.0, 0.0, 0, ctx->dWt, ldw, nullptr);
-      forward_subst_batch(ctx, ctx->dWt, ldw, mbp);
       int vs = std::max(1, std::min(64, Np / 512));
       int cps = (Np + vs - 1) / vs;
-      hipLaunchKernelGGL(gpak_rowsumsq_part_f64, dim3((mbp + 255) / 256, vs), dim3(256), 0, st, ctx->dWt, ldw,
-                         mbp, Np, cps, ctx->dPart, cap);
+      if (f32) {
+        // fp32 arithmetic for the M-proportional work (cross-kernel, substitution, row sums);
+        // the cross-kernel uses the direct distance form (cancellation form is meaningless in fp32)
+        float *Wf = reinterpret_cast<float *>(ctx->dWt);
+        gpak_launch_fill_f32(st, ctx->Tq, ctx->Upred, mbp, Np, kp, Wf, ldw);
+        forward_subst_batch_f32(ctx, Wf, ldw, mbp);
+        gpak_launch_rowsumsq_f32(st, Wf, ldw, mbp, Np, vs, ctx->dPart, cap);
+      } else {
+        gpak_launch_fill(st, ctx->Tq, ctx->Upred, mbp, Np, kp, 1.0, 0.0, 0.0, 0, ctx->dWt, ldw, nullptr);
+        forward_subst_batch(ctx, ctx->dWt, ldw, mbp);
+        hipLaunchKernelGGL(gpak_rowsumsq_part_f64, dim3((mbp + 255) / 256, vs), dim3(256), 0, st, ctx->dWt, ldw,
+                           mbp, Np, cps, ctx->dPart, cap);
+      }
       gpak_launch_sum_splits(st, ctx->dPart, cap, vs, mb, dSq);
       hsq.resize(mb);
       GPAK_HIP(hipMemcpyAsync(hsq.data(), dSq, sizeof(double) * mb, hipMemcpyDeviceToHost, st));

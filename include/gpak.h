@@ -36,10 +36,14 @@ typedef struct gpak_ctx gpak_ctx;
 #define GPAK_EINVAL   2   /* bad argument                                                */
 #define GPAK_ESTATE   3   /* call out of order (e.g. no training set yet)                */
 #define GPAK_ENOMEM   4   /* device allocation failed                                    */
-#define GPAK_ENOTIMPL 5   /* feature not built yet (e.g. precision f32)                  */
+#define GPAK_ENOTIMPL 5   /* feature not built yet (e.g. 4-D inputs)                     */
 #define GPAK_EHIP    (-1) /* HIP runtime error                                           */
 
-/* precision of the device arithmetic (fixed at ctx creation) */
+/* precision (fixed at ctx creation).  GPAK_F64: everything in fp64.  GPAK_F32 (BASELINE.json
+ * configs[4]): the M-proportional prediction work -- cross-kernel, forward substitution with M
+ * right-hand sides, variance row sums -- runs in fp32 on the fp32 MFMA (twice the fp64 matrix
+ * rate); Gram fill, factorisation, alpha, nlZ, gradient and the predictive MEAN stay fp64 (one
+ * 0.2 s factorisation is noise beside a 1e6-point prediction). */
 #define GPAK_F64 0
 #define GPAK_F32 1
 

@@ -114,3 +114,23 @@ def test_reference_style_gradient_matches_oracle(gp, orc, N, mode):
     tol = 1e-8 if mode == gpak.DIST_DIRECT else 1e-5
     assert np.abs(g - go).max() <= tol * scale
     assert g[7] == 0.0
+
+
+def test_fp32_prediction_context(orc):
+    """GPAK_F32 (BASELINE.json configs[4]): fp32 cross-kernel / substitution / variance sums, fp64
+    everything else.  Tolerance: fp32 arithmetic through a triangular solve of a matrix with
+    cond(L) ~ 1e2..1e3 -- 2e-4 relative on the variance, the mean stays at the fp64 bound."""
+    N, M = 1500, 700
+    X, y = synth.drillholes(N)
+    Xte = synth.test_points(M)
+    g32 = gpak.Gpak(0, gpak.F32)
+    g32.set_train(X, y)
+    g32.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    Ko = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+    info, alpha_o, Lo = orc.nlz_lean(Ko, y, SN2)
+    assert abs(g32.logLikelihood() - info.nlz) <= 1e-9 * abs(info.nlz)     # training step is fp64
+    mean, var = g32.posteriorMeanVar(Xte)
+    mo, vo = orc.predict(X, Xte, E, BIAS, SN2, alpha_o, Lo, orc.DIST_DIRECT, 0)
+    assert rel(mean, mo) <= 1e-8
+    assert rel(var, vo) <= 2e-4
+    g32.close()
