@@ -247,16 +247,25 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g) {
     const size_t tot = (size_t)Np * ld;
     hipLaunchKernelGGL(gpak_identity_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, G, ld, Np);
   }
-  for (int jb = 0; jb < T; jb++) {
-    const size_t j0 = (size_t)jb * PB;
-    const double *inv = ctx->dInv + (size_t)jb * 2 * PB * PB;
-    double *Gj = G + j0 * ld;
-    const int mt = jb + 1;  // rows 0 .. j0+127: everything below is zero in L^-T
-    gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Gj, ld, inv, PB, 0.0, Gj, ld, 0, 0, false, false);
-    const int nrest = T - jb - 1;
+  // two levels like the Cholesky: 128-column steps inside an outer block of 512 columns, then one
+  // K = 512 update of the columns to the right; rows beyond the outer block are still zero
+  const int GNB = 512;
+  for (int J = 0; J < Np; J += GNB) {
+    const int W = (Np - J) < GNB ? (Np - J) : GNB;
+    for (int j0 = J; j0 < J + W; j0 += PB) {
+      const double *inv = ctx->dInv + (size_t)(j0 / PB) * 2 * PB * PB;
+      double *Gj = G + (size_t)j0 * ld;
+      const int mt = j0 / PB + 1;  // rows 0 .. j0+127: everything below is zero in L^-T
+      gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Gj, ld, inv, PB, 0.0, Gj, ld, 0, 0, false, false);
+      const int nin = (J + W - j0 - PB) / PB;
+      if (nin > 0)
+        gpak_launch_gemm_nt(st, mt, nin, PB, -1.0, Gj, ld, ctx->dM + (j0 + PB) + (size_t)j0 * ld, ld, 1.0,
+                            G + (size_t)(j0 + PB) * ld, ld, 0, 0, false, false);
+    }
+    const int nrest = (Np - J - W) / PB;
     if (nrest > 0)
-      gpak_launch_gemm_nt(st, mt, nrest, PB, -1.0, Gj, ld, ctx->dM + (j0 + PB) + j0 * ld, ld, 1.0,
-                          G + (j0 + PB) * ld, ld, 0, 0, false, false);
+      gpak_launch_gemm_nt(st, (J + W) / PB, nrest, W, -1.0, G + (size_t)J * ld, ld,
+                          ctx->dM + (J + W) + (size_t)J * ld, ld, 1.0, G + (size_t)(J + W) * ld, ld, 0, 0, false, false);
   }
   // 2. B^-1 = G G^T (lower tiles); G[i,k] = 0 for k < i, so the k-loop starts at the row tile
   gpak_launch_gemm_nt(st, T, T, Np, 1.0, G, ld, G, ld, 0.0, ctx->dBinv, ld, 0, 0, true, true, true);

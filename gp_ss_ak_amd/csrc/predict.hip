@@ -80,21 +80,32 @@ static int ensure_predict_bufs(gpak_ctx *ctx, int cap, bool want_var) {
   return GPAK_OK;
 }
 
-// blocked forward substitution on the test-major batch: Wt (mbp x Np, ld ldw) := Wt * L^-T
+// blocked forward substitution on the test-major batch: Wt (mbp x Np, ld ldw) := Wt * L^-T.
+// Two levels like the Cholesky: inside an outer block of 512 columns the 128-column steps
+// (product with the inverted diagonal block, K = 128 update of the rest of the outer block),
+// then ONE K = 512 update of everything to the right -- 4x less C traffic and 4x more MFMA work
+// per tile than updating the whole remainder after every 128 columns.
+#define FS_NB 512
 static void forward_subst_batch(gpak_ctx *ctx, double *Wt, long ldw, int mbp) {
-  const int Np = ctx->Np, T = Np / PB;
+  const int Np = ctx->Np;
   const long ld = ctx->ld;
   hipStream_t st = ctx->stream;
   const int mt = mbp / PB;
-  for (int jb = 0; jb < T; jb++) {
-    const size_t j0 = (size_t)jb * PB;
-    const double *inv = ctx->dInv + (size_t)jb * 2 * PB * PB;
-    double *Wj = Wt + j0 * ldw;
-    gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Wj, ldw, inv, PB, 0.0, Wj, ldw, 0, 0, false, false);
-    const int nrest = T - jb - 1;
+  for (int J = 0; J < Np; J += FS_NB) {
+    const int W = std::min(FS_NB, Np - J);
+    for (int j0 = J; j0 < J + W; j0 += PB) {
+      const double *inv = ctx->dInv + (size_t)(j0 / PB) * 2 * PB * PB;
+      double *Wj = Wt + (size_t)j0 * ldw;
+      gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Wj, ldw, inv, PB, 0.0, Wj, ldw, 0, 0, false, false);
+      const int nin = (J + W - j0 - PB) / PB;
+      if (nin > 0)
+        gpak_launch_gemm_nt(st, mt, nin, PB, -1.0, Wj, ldw, ctx->dM + (j0 + PB) + (size_t)j0 * ld, ld, 1.0,
+                            Wt + (size_t)(j0 + PB) * ldw, ldw, 0, 0, false, false);
+    }
+    const int nrest = (Np - J - W) / PB;
     if (nrest > 0)
-      gpak_launch_gemm_nt(st, mt, nrest, PB, -1.0, Wj, ldw, ctx->dM + (j0 + PB) + j0 * ld, ld, 1.0,
-                          Wt + (j0 + PB) * ldw, ldw, 0, 0, false, false);
+      gpak_launch_gemm_nt(st, mt, nrest, W, -1.0, Wt + (size_t)J * ldw, ldw, ctx->dM + (J + W) + (size_t)J * ld, ld,
+                          1.0, Wt + (size_t)(J + W) * ldw, ldw, 0, 0, false, false);
   }
 }
 
@@ -115,20 +126,26 @@ static int ensure_f32_factor(gpak_ctx *ctx) {
   return GPAK_OK;
 }
 
-// the same blocked forward substitution in fp32 (v_mfma_f32_16x16x4_f32)
+// the same two-level forward substitution in fp32 (v_mfma_f32_16x16x4_f32)
 static void forward_subst_batch_f32(gpak_ctx *ctx, float *Wt, long ldw, int mbp) {
-  const int Np = ctx->Np, T = Np / PB;
+  const int Np = ctx->Np;
   hipStream_t st = ctx->stream;
   const int mt = mbp / PB;
-  for (int jb = 0; jb < T; jb++) {
-    const size_t j0 = (size_t)jb * PB;
-    const float *inv = ctx->dInvf + (size_t)jb * 2 * PB * PB;
-    float *Wj = Wt + j0 * ldw;
-    gpak_launch_gemm_nt_f32(st, mt, 1, PB, 1.f, Wj, ldw, inv, PB, 0.f, Wj, ldw);
-    const int nrest = T - jb - 1;
+  for (int J = 0; J < Np; J += FS_NB) {
+    const int W = std::min(FS_NB, Np - J);
+    for (int j0 = J; j0 < J + W; j0 += PB) {
+      const float *inv = ctx->dInvf + (size_t)(j0 / PB) * 2 * PB * PB;
+      float *Wj = Wt + (size_t)j0 * ldw;
+      gpak_launch_gemm_nt_f32(st, mt, 1, PB, 1.f, Wj, ldw, inv, PB, 0.f, Wj, ldw);
+      const int nin = (J + W - j0 - PB) / PB;
+      if (nin > 0)
+        gpak_launch_gemm_nt_f32(st, mt, nin, PB, -1.f, Wj, ldw, ctx->dLf + (j0 + PB) + (size_t)j0 * Np, Np, 1.f,
+                                Wt + (size_t)(j0 + PB) * ldw, ldw);
+    }
+    const int nrest = (Np - J - W) / PB;
     if (nrest > 0)
-      gpak_launch_gemm_nt_f32(st, mt, nrest, PB, -1.f, Wj, ldw, ctx->dLf + (j0 + PB) + j0 * Np, Np, 1.f,
-                              Wt + (j0 + PB) * ldw, ldw);
+      gpak_launch_gemm_nt_f32(st, mt, nrest, W, -1.f, Wt + (size_t)J * ldw, ldw, ctx->dLf + (J + W) + (size_t)J * Np,
+                              Np, 1.f, Wt + (size_t)(J + W) * ldw, ldw);
   }
 }
 
