@@ -1,6 +1,6 @@
 // host_selftest.cpp -- exercises the class surface the way the reference's own call sites do
 // (gp_ss_ak.cpp:139-303, 376-412) and prints one JSON object; tests/test_host_cpp.py compares
-// it with the oracle.  Usage: host_selftest train.csv test.csv
+// it with the CPU checker.  Usage: host_selftest train.csv test.csv
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
