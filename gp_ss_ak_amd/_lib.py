@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgpak_hip.so")
 # every symbol include/gpak.h declares (tests check the header and this list agree)
 SYMBOLS = [
     "gpak_create", "gpak_destroy", "gpak_last_error", "gpak_global_error", "gpak_set_train",
-    "gpak_set_params", "gpak_set_option", "gpak_gram", "gpak_compute_k", "gpak_factor",
+    "gpak_set_params", "gpak_set_kernel", "gpak_set_option", "gpak_gram", "gpak_compute_k", "gpak_factor",
     "gpak_get_chol_upper", "gpak_failed_column", "gpak_solve_alpha", "gpak_solve_chol", "gpak_nlz",
     "gpak_nlz_terms", "gpak_predict", "gpak_grad", "gpak_timing", "gpak_calibrate",
 ]
@@ -52,6 +52,7 @@ def load():
     lib.gpak_global_error.restype = C.c_char_p
     lib.gpak_set_train.argtypes = [vp, dp, dp, C.c_int, C.c_int]
     lib.gpak_set_params.argtypes = [vp, dp, C.c_double, C.c_double, C.c_int]
+    lib.gpak_set_kernel.argtypes = [vp, C.c_int, C.POINTER(C.c_int), dp, C.c_double, C.c_double, C.c_double, C.c_int]
     lib.gpak_set_option.argtypes = [vp, C.c_int, C.c_long]
     lib.gpak_gram.argtypes = [vp, dp, dp]
     lib.gpak_compute_k.argtypes = [vp, dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]

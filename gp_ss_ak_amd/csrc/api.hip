@@ -18,18 +18,18 @@ static std::string g_global_err;
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static void free_points(DevPoints &p) {
-  if (p.u0) hipFree(p.u0);
+  if (p.base) hipFree(p.base);
   p = DevPoints();
 }
 int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap) {
   if (p.cap >= cap) return GPAK_OK;
   free_points(p);
   double *base = nullptr;
-  if (hipMalloc(&base, sizeof(double) * 4 * (size_t)cap) != hipSuccess) {
+  if (hipMalloc(&base, sizeof(double) * 4 * GPAK_MAX_TERMS * (size_t)cap) != hipSuccess) {
     ctx->err = "hipMalloc(points) failed";
     return GPAK_ENOMEM;
   }
-  p.u0 = base; p.u1 = base + cap; p.u2 = base + 2 * (size_t)cap; p.s = base + 3 * (size_t)cap;
+  p.base = base;
   p.cap = cap;
   return GPAK_OK;
 }
@@ -216,16 +216,65 @@ int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2
   memcpy(ctx->expans, expans, sizeof(double) * 8);
   ctx->bias = bias; ctx->sn2 = sn2; ctx->dist_mode = dist_mode;
   ctx->have_params = true;
-  gpak_build_siginv(expans, ctx->kp.A);
-  ctx->kp.var2 = expans[6] * expans[6];
+  ctx->expans_only = true;
+  ctx->kp.nterms = 1;
+  gpak_build_siginv(expans, ctx->kp.term[0].A);
+  ctx->kp.term[0].var2 = expans[6] * expans[6];
+  ctx->kp.term[0].iw = 0.0;
+  ctx->kp.term[0].profile = GPAK_PROFILE_EXPSQRT;
   ctx->kp.bias = bias;
+  ctx->kp.white = 0.0;
   ctx->kp.mode = dist_mode;
+  ctx->kdiag = expans[6] * expans[6] + bias;
   if (!(same && ctx->memoise)) {
     // GP_Utils.cpp:132-133: setKUpdateStat(false) -> K, alpha and the likelihood are stale
     ctx->mstate = gpak_ctx::M_NONE;
     ctx->alpha_ok = ctx->nlz_ok = false;
     ctx->U.n = 0;
   }
+  return GPAK_OK;
+}
+
+// general composition: kinds[t] in {GPAK_KERN_EXPANS, GPAK_KERN_EXP, GPAK_KERN_RBF}, pars = the children's
+// parameters concatenated in the reference's order (8 / 2 / 3 values)
+int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *pars, double bias, double white,
+                    double sn2, int dist_mode) {
+  if (!ctx || !kinds || !pars || nterms < 1 || nterms > GPAK_MAX_TERMS) return GPAK_EINVAL;
+  if (dist_mode != GPAK_DIST_EXPANSION && dist_mode != GPAK_DIST_DIRECT) { ctx->err = "bad dist_mode"; return GPAK_EINVAL; }
+  KernParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.nterms = nterms;
+  double kdiag = bias + white;
+  const double *p = pars;
+  for (int t = 0; t < nterms; t++) {
+    KernTerm &T = kp.term[t];
+    if (kinds[t] == GPAK_KERN_EXPANS) {
+      gpak_build_siginv(p, T.A);
+      T.var2 = p[6] * p[6]; T.profile = GPAK_PROFILE_EXPSQRT;
+      if (t == 0) memcpy(ctx->expans, p, sizeof(double) * 8);
+      p += 8;
+    } else if (kinds[t] == GPAK_KERN_EXP) {   // {Hayper_Euc_Exp, Sigma_Exp}, Kernel.cpp:576-600
+      const double s = 1.0 / p[0];             // mlA: X * hyp^-2 on one side == both sides scaled by 1/hyp
+      T.A[0] = T.A[4] = T.A[8] = s;
+      T.var2 = p[1] * p[1]; T.profile = GPAK_PROFILE_EXPSQRT;
+      p += 2;
+    } else if (kinds[t] == GPAK_KERN_RBF) {   // {Hayper_Euc_RBF, inverseWidth_RBF, Sigma_RBF}, Kernel.cpp:411-428
+      const double s = 1.0 / p[0];
+      T.A[0] = T.A[4] = T.A[8] = s;
+      T.iw = p[1]; T.var2 = p[2] * p[2]; T.profile = GPAK_PROFILE_RBF;
+      p += 3;
+    } else { ctx->err = "unknown kernel kind"; return GPAK_EINVAL; }
+    kdiag += T.var2;
+  }
+  kp.bias = bias; kp.white = white; kp.mode = dist_mode;
+  ctx->kp = kp;
+  ctx->kdiag = kdiag;
+  ctx->expans_only = (nterms == 1 && kinds[0] == GPAK_KERN_EXPANS && white == 0.0);
+  ctx->bias = bias; ctx->sn2 = sn2; ctx->dist_mode = dist_mode;
+  ctx->have_params = true;
+  ctx->mstate = gpak_ctx::M_NONE;
+  ctx->alpha_ok = ctx->nlz_ok = false;
+  ctx->U.n = 0;
   return GPAK_OK;
 }
 
@@ -308,7 +357,8 @@ static int ensure_nlz(gpak_ctx *ctx) {
   double *scratch = ctx->dWork + 4 * (size_t)ctx->Np;  // 64 * Np doubles available
   GPAK_HIP(hipEventRecord(ctx->ev[5], st));
   int splits = gpak_kmatvec_splits(ctx->N, ctx->N);
-  gpak_launch_kmatvec(st, ctx->U, ctx->dAlpha, ctx->U, ctx->kp, scratch, splits, f);  // f = K*Alpha
+  gpak_launch_kmatvec(st, ctx->U, 0, ctx->N, ctx->dAlpha, ctx->U, ctx->kp, scratch, splits, f);  // f = K*Alpha
+  if (ctx->kp.white != 0.0) gpak_launch_axpy(st, ctx->N, ctx->kp.white, ctx->dAlpha, f);  // Kern_White diagonal
   gpak_launch_logdet(st, ctx->N, ctx->dM, ctx->ld, ctx->dRed);
   gpak_launch_nlz_terms(st, ctx->N, ctx->dy, f, ctx->dAlpha, ctx->sn2, ctx->dRed);
   double red[3];
@@ -371,6 +421,7 @@ int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int
   }
   KernParams kp = ctx->kp;
   gpak_pooled_mean(s1, n, s2, m, kp.mu);
+  if (!(X1[0] == X2[0] && n == m)) kp.white = 0.0;  // Kern_White::computeK, Kernel.cpp:260-262
   DevPoints P, Q;
   double *dx = nullptr, *dK = nullptr, *dD2 = nullptr;
   int rc = gpak_alloc_points(ctx, P, np);
@@ -490,6 +541,7 @@ int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, 
 
 int gpak_grad(gpak_ctx *ctx, double *g) {
   if (!ctx || !g) return GPAK_EINVAL;
+  if (!ctx->expans_only) { ctx->err = "gpak_grad handles the ExpAns(+Bias) composition only"; return GPAK_ENOTIMPL; }
   int rc = ensure_nlz(ctx);  // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
   if (rc) return rc;
   return gpak_grad_impl(ctx, g);

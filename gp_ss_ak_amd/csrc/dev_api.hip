@@ -1,25 +1,29 @@
 // dev_api.hip -- device-pointer level C-ABI (include/gpak_dev.h): what one rank of the
 // block-column-cyclic multi-GPU factorisation runs on the block columns it owns.
 #include <cmath>
+#include <cstring>
 
 #include "../../include/gpak_dev.h"
 #include "gpak_internal.h"
 
 void gpak_build_siginv(const double *e, double *A);
 
+// view of points [off, n) of a transformed set: same array stride (cap), shifted base
 static DevPoints as_points(const double *u, int cap, int n, int off = 0) {
   DevPoints p;
-  double *b = const_cast<double *>(u);
-  p.u0 = b + off; p.u1 = b + cap + off; p.u2 = b + 2 * (size_t)cap + off; p.s = b + 3 * (size_t)cap + off;
+  p.base = const_cast<double *>(u) + off;
   p.n = n - off;
-  p.cap = cap - off;
+  p.cap = cap;
   return p;
 }
 static KernParams make_kp(const double *expans, double bias, int mode, const double *mu) {
   KernParams kp;
-  gpak_build_siginv(expans, kp.A);
+  memset(&kp, 0, sizeof(kp));
+  kp.nterms = 1;
+  gpak_build_siginv(expans, kp.term[0].A);
+  kp.term[0].var2 = expans[6] * expans[6];
+  kp.term[0].profile = GPAK_PROFILE_EXPSQRT;
   for (int k = 0; k < 3; k++) kp.mu[k] = mu ? mu[k] : 0.0;
-  kp.var2 = expans[6] * expans[6];
   kp.bias = bias;
   kp.mode = mode;
   return kp;
@@ -111,10 +115,8 @@ int gpak_dev_kmatvec(void *stream, const double *u, int cap, int n, int i0, int 
                      const double *expans, double bias, int dist_mode, double *scratch, double *out) {
   KernParams kp = make_kp(expans, bias, dist_mode, nullptr);
   DevPoints Q = as_points(u, cap, n);
-  DevPoints P = as_points(u, cap, i1, i0);  // source points [i0, i1)
-  P.cap = Q.cap;
-  int splits = gpak_kmatvec_splits(P.n, Q.n);
-  gpak_launch_kmatvec((hipStream_t)stream, P, w + i0, Q, kp, scratch, splits, out);
+  int splits = gpak_kmatvec_splits(i1 - i0, Q.n);
+  gpak_launch_kmatvec((hipStream_t)stream, Q, i0, i1 - i0, w + i0, Q, kp, scratch, splits, out);  // source points [i0, i1)
   return status();
 }
 

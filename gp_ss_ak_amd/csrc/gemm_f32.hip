@@ -127,33 +127,45 @@ void gpak_launch_vec_to_f32(hipStream_t st, const double *in, size_t n, float *o
 
 // ---- fp32 cross-kernel fill (test-major batch) and row sums of squares ------------------------
 // distance in fp64 from the fp64 coordinates (three subtractions), profile sqrt/exp in fp32
-__global__ __launch_bounds__(256) void gpak_fill_f32(const double *__restrict__ pu0, const double *__restrict__ pu1,
-                                                      const double *__restrict__ pu2, int nP,
-                                                      const double *__restrict__ qu0, const double *__restrict__ qu1,
-                                                      const double *__restrict__ qu2, int nQ, float var2, float bias,
+#define PARR32(base, cap, t, c) ((base) + (size_t)(4 * (t) + (c)) * (cap))
+__global__ __launch_bounds__(256) void gpak_fill_f32(const double *__restrict__ P, int capP, int nP,
+                                                      const double *__restrict__ Q, int capQ, int nQ, KernParams kp,
                                                       float *__restrict__ C, long ld) {
   const int row0 = blockIdx.x * 128, col0 = blockIdx.y * 64;
-  __shared__ double q[3][64];
+  __shared__ double q[GPAK_MAX_TERMS][3][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int nterms = kp.nterms;
   if (t < 64) {
     const int j = col0 + t;
     const bool ok = j < nQ;
-    q[0][t] = ok ? qu0[j] : 0.0; q[1][t] = ok ? qu1[j] : 0.0; q[2][t] = ok ? qu2[j] : 0.0;
+    for (int m = 0; m < nterms; m++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) q[m][c][t] = ok ? PARR32(Q, capQ, m, c)[j] : 0.0;
   }
   const int r = row0 + 2 * lane;
-  const double2 a0 = *reinterpret_cast<const double2 *>(pu0 + r);
-  const double2 a1 = *reinterpret_cast<const double2 *>(pu1 + r);
-  const double2 a2 = *reinterpret_cast<const double2 *>(pu2 + r);
+  double2 a[GPAK_MAX_TERMS][3];
+  for (int m = 0; m < nterms; m++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) a[m][c] = *reinterpret_cast<const double2 *>(PARR32(P, capP, m, c) + r);
   __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
   for (int c = 0; c < 16; c++) {
     const int jl = w + 4 * c, j = col0 + jl;
-    const double b0 = q[0][jl], b1 = q[1][jl], b2 = q[2][jl];
-    double dx = a0.x - b0, dy = a1.x - b1, dz = a2.x - b2;
-    const float d0 = (float)(dx * dx + dy * dy + dz * dz);
-    dx = a0.y - b0; dy = a1.y - b1; dz = a2.y - b2;
-    const float d1 = (float)(dx * dx + dy * dy + dz * dz);
-    float k0 = var2 * __expf(-sqrtf(d0)) + bias, k1 = var2 * __expf(-sqrtf(d1)) + bias;
+    float k0 = (float)kp.bias, k1 = (float)kp.bias;
+    for (int m = 0; m < nterms; m++) {
+      const double b0 = q[m][0][jl], b1 = q[m][1][jl], b2 = q[m][2][jl];
+      double dx = a[m][0].x - b0, dy = a[m][1].x - b1, dz = a[m][2].x - b2;
+      const float d0 = (float)(dx * dx + dy * dy + dz * dz);
+      dx = a[m][0].y - b0; dy = a[m][1].y - b1; dz = a[m][2].y - b2;
+      const float d1 = (float)(dx * dx + dy * dy + dz * dz);
+      const float v2 = (float)kp.term[m].var2;
+      if (kp.term[m].profile == GPAK_PROFILE_RBF) {
+        const float hw = -0.5f * (float)kp.term[m].iw;
+        k0 += v2 * __expf(hw * d0); k1 += v2 * __expf(hw * d1);
+      } else {
+        k0 += v2 * __expf(-sqrtf(d0)); k1 += v2 * __expf(-sqrtf(d1));
+      }
+    }
     const bool cj = j < nQ;
     if (!(cj && r < nP)) k0 = 0.f;
     if (!(cj && r + 1 < nP)) k1 = 0.f;
@@ -163,8 +175,7 @@ __global__ __launch_bounds__(256) void gpak_fill_f32(const double *__restrict__ 
 void gpak_launch_fill_f32(hipStream_t st, const DevPoints &P, const DevPoints &Q, int rows_p, int cols_p,
                           const KernParams &kp, float *C, long ld) {
   dim3 grid(rows_p / 128, cols_p / 64);
-  hipLaunchKernelGGL(gpak_fill_f32, grid, dim3(256), 0, st, P.u0, P.u1, P.u2, P.n, Q.u0, Q.u1, Q.u2, Q.n,
-                     (float)kp.var2, (float)kp.bias, C, ld);
+  hipLaunchKernelGGL(gpak_fill_f32, grid, dim3(256), 0, st, P.base, P.cap, P.n, Q.base, Q.cap, Q.n, kp, C, ld);
 }
 
 __global__ __launch_bounds__(256) void gpak_rowsumsq_part_f32(const float *__restrict__ V, long ldv, int rows, int cols,

@@ -9,19 +9,34 @@
 
 #define GPAK_TILE 128  // every matrix dimension on the device is padded to this
 
-// Parameters of the fused ExpAns+Bias kernel function, as the device sees them.
-// A = sigInv = Rot * diag(L) * Rot^T   (Kernel.cpp:1399-1425), built on the host.
+// The covariance function as the device sees it: a SUM of up to three stationary terms (the
+// children of the reference's HybKerns, Kernel.cpp:140-154), a constant and a white-noise diagonal.
+//   term t:  k_t(x, x') = var2 * profile( D2_t ),  D2_t = |(x - x') A_t|^2
+//   profile 0: exp(-sqrt(D2))        Kern_ExpAnisotropic (A = Rot diag(L) Rot^T, Kernel.cpp:1399-1425)
+//                                    Kern_Exponential    (A = I / Hayper_Euc_Exp, Kernel.cpp:1343-1368, 1437-1441)
+//   profile 1: exp(-0.5 * iw * D2)   Kern_RBF            (A = I / Hayper_Euc_RBF, Kernel.cpp:482-488)
+#define GPAK_MAX_TERMS 3
+#define GPAK_PROFILE_EXPSQRT 0
+#define GPAK_PROFILE_RBF 1
+struct KernTerm {
+  double A[9];   // column-major 3x3 metric factor
+  double var2;   // Sigma^2
+  double iw;     // inverseWidth_RBF (profile 1 only)
+  int profile;
+};
 struct KernParams {
-  double A[9];   // column-major 3x3
+  KernTerm term[GPAK_MAX_TERMS];
+  int nterms;
   double mu[3];  // pooled mean used for centring (Kernel.cpp:1391-1397)
-  double var2;   // Sigma_ExpAns^2   (Kernel.cpp:861)
-  double bias;   // Sigma_Bias       (Kernel.cpp:366)
+  double bias;   // Kern_Bias Sigma_Bias (Kernel.cpp:366), added to every entry
+  double white;  // Kern_White Sigma_White (Kernel.cpp:256-263), added where i == j of the same set
   int mode;      // GPAK_DIST_*
 };
 
-// A transformed point set on the device: u = (x - mu) A, SoA, plus |u|^2.
+// A transformed point set on the device: for each term u = (x - mu) A_t, SoA, plus |u|^2:
+// array c (0..2 = u0,u1,u2; 3 = |u|^2) of term t is base + (4 t + c) * cap.
 struct DevPoints {
-  double *u0 = nullptr, *u1 = nullptr, *u2 = nullptr, *s = nullptr;
+  double *base = nullptr;
   int n = 0;    // valid points
   int cap = 0;  // allocated points (multiple of GPAK_TILE)
 };
@@ -42,10 +57,12 @@ struct gpak_ctx {
 
   // parameters
   bool have_params = false;
-  double expans[8] = {0};
+  double expans[8] = {0};   // ExpAns parameters when the kernel is the reference's default composition
+  bool expans_only = true;  // kernel == ExpAns(+Bias): the only composition gpak_grad handles
   double bias = 0, sn2 = 0;
   int dist_mode = GPAK_DIST_DIRECT;
   KernParams kp;
+  double kdiag = 0;          // diag_Compute of the composition (Kernel.cpp:127-136)
 
   // device state
   DevPoints U;               // transformed training points
@@ -118,7 +135,7 @@ void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, in
 // out_j = sum_i w_i K(P_i, Q_j), j < Q.n   (fused Gram-matvec; K never stored).
 // scratch holds splits * Q.cap doubles.
 int gpak_kmatvec_splits(int nP, int nQ);
-void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, const double *w, const DevPoints &Q,
+void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, int p_off, int np, const double *w, const DevPoints &Q,
                          const KernParams &kp, double *scratch, int splits, double *out);
 void gpak_launch_sum_splits(hipStream_t st, const double *part, int part_ld, int splits, int n, double *out);
 int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap);
@@ -174,6 +191,7 @@ void gpak_launch_logdet(hipStream_t st, int N, const double *L, long ld, double 
 void gpak_launch_nlz_terms(hipStream_t st, int N, const double *y, const double *f, const double *alpha,
                            double sn2, double *red);
 void gpak_launch_scale(hipStream_t st, int n, const double *in, double s, double *out);
+void gpak_launch_axpy(hipStream_t st, int n, double a, const double *x, double *y);  // y += a x
 
 // ---- predict.hip ------------------------------------------------------------------------
 void gpak_predict_release(gpak_ctx *ctx);

@@ -272,7 +272,7 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g) {
   // 3. fused pair pass
   GradConsts gc;
   build_grad_consts(ctx->expans, gc);
-  gc.var2 = ctx->kp.var2; gc.bias = ctx->bias; gc.sn2 = ctx->sn2; gc.mode = ctx->dist_mode;
+  gc.var2 = ctx->kp.term[0].var2; gc.bias = ctx->bias; gc.sn2 = ctx->sn2; gc.mode = ctx->dist_mode;
   dim3 grid(Np / GT_ROWS, Np / GT_COLS);
   const size_t nblocks = (size_t)grid.x * grid.y;
   if (ctx->gpart_elems < nblocks * NSUM) {
@@ -286,7 +286,7 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g) {
   }
   int rc = gpak_ensure_U(ctx);
   if (rc) return rc;
-  hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, ctx->U.u0, ctx->U.u1, ctx->U.u2, ctx->U.s,
+  hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, ctx->U.base, ctx->U.base + ctx->U.cap, ctx->U.base + 2 * (size_t)ctx->U.cap, ctx->U.base + 3 * (size_t)ctx->U.cap,
                      ctx->dX, ctx->dX + Np, ctx->dX + 2 * (size_t)Np, ctx->dAlpha, ctx->dBinv, ld, N, gc,
                      ctx->dGpart);
   hipLaunchKernelGGL(gpak_grad_reduce_f64, dim3(NSUM), dim3(256), 0, st, ctx->dGpart, (int)nblocks, ctx->dRed + 8);

@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void gpak_rowsumsq_part_f64(const double *__re
 }
 
 void gpak_predict_release(gpak_ctx *ctx) {
-  if (ctx->Upred.u0) hipFree(ctx->Upred.u0);
-  if (ctx->Tq.u0) hipFree(ctx->Tq.u0);
+  if (ctx->Upred.base) hipFree(ctx->Upred.base);
+  if (ctx->Tq.base) hipFree(ctx->Tq.base);
   ctx->Upred = DevPoints(); ctx->Tq = DevPoints();
   if (ctx->dXte) hipFree(ctx->dXte);
   if (ctx->dWt) hipFree(ctx->dWt);
@@ -174,7 +174,8 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   gpak_pooled_mean(ctx->xsum, N, s2, M, kp.mu);
   gpak_launch_transform(st, ctx->dX, Np, N, kp, ctx->Upred);
 
-  const double kD = ctx->expans[6] * ctx->expans[6] + ctx->bias;  // diag_Compute, Kernel.cpp:780-783, 328-332
+  const double kD = ctx->kdiag;  // diag_Compute of the composition, Kernel.cpp:127-136, 780-783, 328-332
+  kp.white = 0.0;                // Kern_White contributes nothing to a train x test block (Kernel.cpp:260-262)
   double *dMean = ctx->dPv, *dSq = ctx->dPv + cap;
   std::vector<double> hsq;
   for (long b0 = 0; b0 < M; b0 += cap) {
@@ -187,7 +188,7 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
     gpak_launch_transform(st, ctx->dXte, cap, mb, kp, ctx->Tq);
     // _postMean: mu_t = Alpha . kX(:,t)
     int splits = gpak_kmatvec_splits(N, mb);
-    gpak_launch_kmatvec(st, ctx->Upred, ctx->dAlpha, ctx->Tq, kp, ctx->dPart, splits, dMean);
+    gpak_launch_kmatvec(st, ctx->Upred, 0, N, ctx->dAlpha, ctx->Tq, kp, ctx->dPart, splits, dMean);
     GPAK_HIP(hipMemcpyAsync(mean + b0, dMean, sizeof(double) * mb, hipMemcpyDeviceToHost, st));
     if (var) {
       const long ldw = cap;

@@ -218,6 +218,14 @@ __global__ void gpak_scale_f64(int n, const double *__restrict__ in, double s, d
   if (i < n) out[i] = in[i] * s;
 }
 
+__global__ void gpak_axpy_f64(int n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = fma(a, x[i], y[i]);
+}
+void gpak_launch_axpy(hipStream_t st, int n, double a, const double *x, double *y) {
+  hipLaunchKernelGGL(gpak_axpy_f64, dim3((n + 255) / 256), dim3(256), 0, st, n, a, x, y);
+}
+
 void gpak_launch_logdet(hipStream_t st, int N, const double *L, long ld, double *red) {
   hipLaunchKernelGGL(gpak_logdet_f64, dim3(1), dim3(1024), 0, st, N, L, ld, red);
 }

@@ -16,6 +16,7 @@ F64, F32 = 0, 1
 DIST_EXPANSION, DIST_DIRECT = 0, 1
 COMPAT_VARCLAMP, COMPAT_SN2SKIP = 1, 2
 OPT_MEMOISE, OPT_NB_OUTER, OPT_PROFILE, OPT_LOOKAHEAD = 1, 2, 3, 4
+KERN_EXPANS, KERN_EXP, KERN_RBF = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 
@@ -72,6 +73,13 @@ class Gpak:
         e = np.ascontiguousarray(expans, dtype=np.float64)
         assert e.size == 8
         self._check(self._lib.gpak_set_params(self._h, _p(e), float(bias), float(sn2), int(dist_mode)))
+
+    def set_kernel(self, terms, bias, white, sn2, dist_mode=DIST_DIRECT):
+        """General HybKerns composition: terms = [(KERN_*, [parameters in the reference's order]), ...]."""
+        kinds = (C.c_int * len(terms))(*[int(k) for k, _ in terms])
+        pars = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64) for _, p in terms]))
+        self._check(self._lib.gpak_set_kernel(self._h, len(terms), kinds, _p(pars), float(bias), float(white),
+                                              float(sn2), int(dist_mode)))
 
     # -- hot path ------------------------------------------------------------------------
     def gram(self, want_d2=False):

@@ -62,7 +62,10 @@ void GP_Cntrl::train() {
   for (auto &k : KernT) {
     if (k == "ExpAns") { Kern_ExpAnisotropic e(X); Kerns.addNewKernel(&e); }
     else if (k == "Bias") { Kern_Bias b(X); Kerns.addNewKernel(&b); }
-    else ErrorTermination("Covariance function " + k + " is not on the HIP path (ExpAns, Bias)");
+    else if (k == "RBF") { Kern_RBF r(X); Kerns.addNewKernel(&r); }
+    else if (k == "Exp") { Kern_Exponential e(X); Kerns.addNewKernel(&e); }
+    else if (k == "White") { Kern_White w(X); Kerns.addNewKernel(&w); }
+    else ErrorTermination("Unknown covariance function: " + k);
   }
   if (Kerns.getNumKerns() == 0) { Kern_ExpAnisotropic e(X); Kerns.addNewKernel(&e); }
   if (Knoise) { Kern_Bias b(X); Kerns.addNewKernel(&b); }

@@ -62,12 +62,19 @@ void GP_utils::set_GP_Pars(mat &param) const {  // GP_Utils.cpp:130-157: always 
 
 void GP_utils::sync_params() const {
   if (!dirty) return;
-  double e[8], bias;
-  if (!gpak_extract_expans_bias(KerenlW, e, &bias)) {
-    std::cerr << "GP_utils: the HIP path handles ExpAns(+Bias) kernels only." << std::endl;
-    exit(1);
+  double e[8], bias, white;
+  if (gpak_extract_expans_bias(KerenlW, e, &bias)) {
+    if (gpak_set_params(ctx, e, bias, hyperlf(0), gpak_host_dist_mode()) != GPAK_OK) gpak_host_fatal("gpak_set_params", ctx);
+  } else {
+    std::vector<int> kinds;
+    std::vector<double> pars;
+    if (!gpak_extract_composition(KerenlW, kinds, pars, &bias, &white) || kinds.empty()) {
+      std::cerr << "GP_utils: this kernel composition is not on the HIP path." << std::endl;
+      exit(1);
+    }
+    if (gpak_set_kernel(ctx, (int)kinds.size(), kinds.data(), pars.data(), bias, white, hyperlf(0), gpak_host_dist_mode()) != GPAK_OK)
+      gpak_host_fatal("gpak_set_kernel", ctx);
   }
-  if (gpak_set_params(ctx, e, bias, hyperlf(0), gpak_host_dist_mode()) != GPAK_OK) gpak_host_fatal("gpak_set_params", ctx);
   dirty = false;
 }
 

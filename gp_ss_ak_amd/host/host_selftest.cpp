@@ -149,6 +149,19 @@ int main(int argc, char **argv) {
   gp.set_GP_Pars(p);
   double bad = gp.logLikelihood();
   printf("\"chol_fail_is_nan\": %s,\n", bad != bad ? "true" : "false");
+  // f-4: another composition through the same classes: ExpAns + RBF + Exp + Bias + White
+  {
+    HybKerns H2(X);
+    Kern_RBF rbf(X); Kern_Exponential ex(X); Kern_White wh(X);
+    H2.addNewKernel(&ea); H2.addNewKernel(&rbf); H2.addNewKernel(&ex); H2.addNewKernel(&kb); H2.addNewKernel(&wh);
+    mat K2, D22;
+    H2.computeK(X, X, K2, D22);
+    double s2 = 0;
+    for (size_t i = 0; i < K2.n_elem; i++) s2 += K2[i];
+    GP_utils gp2(&H2, X, y, GP_utils::inf_laplace, GP_utils::likeL_Gaussian, GP_utils::mean_zero, 8, 1, 0, 0);
+    printf("\"hyb5_npars\": %u,\n\"hyb5_K_sum\": %.17g,\n\"hyb5_K00\": %.17g,\n\"hyb5_nlz\": %.17g,\n", gp2.getNumPars(), s2,
+           K2(0, 0), gp2.logLikelihood());
+  }
   // model file round trip
   p(9) = 0.016;
   gp.set_GP_Pars(p);

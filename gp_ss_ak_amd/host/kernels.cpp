@@ -176,6 +176,90 @@ void Kern_Bias::computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const { 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kern_Exponential / Kern_RBF / Kern_White
+// ---------------------------------------------------------------------------------------------
+static void device_compute_composition(const Kernels *k, const mat &X1, const mat &X2, mat &K, mat &D2) {
+  std::vector<int> kinds;
+  std::vector<double> pars;
+  double bias, white;
+  if (!gpak_extract_composition(k, kinds, pars, &bias, &white) || kinds.empty()) {
+    std::cerr << "computeK: composition not on the HIP path" << std::endl;
+    exit(1);
+  }
+  gpak_ctx *ctx = gpak_host_scratch_ctx();
+  if (gpak_set_kernel(ctx, (int)kinds.size(), kinds.data(), pars.data(), bias, white, 1.0, gpak_host_dist_mode()) != GPAK_OK)
+    gpak_host_fatal("gpak_set_kernel", ctx);
+  if (K.n_rows != X1.n_rows || K.n_cols != X2.n_rows) K.resize(X1.n_rows, X2.n_rows);
+  if (D2.n_rows != X1.n_rows || D2.n_cols != X2.n_rows) D2.resize(X1.n_rows, X2.n_rows);
+  if (gpak_compute_k(ctx, X1.memptr(), (int)X1.n_rows, X2.memptr(), (int)X2.n_rows, (int)X1.n_cols, K.memptr(),
+                     D2.memptr()) != GPAK_OK)
+    gpak_host_fatal("gpak_compute_k", ctx);
+}
+void Kern_Exponential::_init() {
+  nParams = 2;
+  setKerName("Exp");
+  setParamName("Hayper_Euc_Exp", 0);
+  setParamName("Sigma_Exp", 1);
+  setInitPars();
+}
+void Kern_Exponential::setParam(double val, unsigned int paramNo) {
+  if (paramNo == 0) Hayper_Euc_Exp = val;
+  else if (paramNo == 1) Sigma_Exp = val;
+  else { std::cout << "Requested parameter doesn't exist.\n"; exit(1); }
+}
+double Kern_Exponential::getParam(unsigned int paramNo) const {
+  if (paramNo == 0) return Hayper_Euc_Exp;
+  if (paramNo == 1) return Sigma_Exp;
+  std::cout << "Requested parameter doesn't exist.\n"; exit(1);
+}
+void Kern_Exponential::computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const { device_compute_composition(this, X1, X2, K, D2); }
+
+void Kern_RBF::_init() {
+  nParams = 3;
+  setKerName("RBF");
+  setParamName("Hayper_Euc_RBF", 0);
+  setParamName("inverseWidth_RBF", 1);
+  setParamName("Sigma_RBF", 2);
+  setInitPars();
+}
+void Kern_RBF::setParam(double val, unsigned int paramNo) {
+  if (paramNo == 0) Hayper_Euc_RBF = val;
+  else if (paramNo == 1) inverseWidth_RBF = val;
+  else if (paramNo == 2) Sigma_RBF = val;
+  else { std::cout << "Requested parameter doesn't exist.\n"; exit(1); }
+}
+double Kern_RBF::getParam(unsigned int paramNo) const {
+  if (paramNo == 0) return Hayper_Euc_RBF;
+  if (paramNo == 1) return inverseWidth_RBF;
+  if (paramNo == 2) return Sigma_RBF;
+  std::cout << "Requested parameter doesn't exist.\n"; exit(1);
+}
+void Kern_RBF::computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const { device_compute_composition(this, X1, X2, K, D2); }
+
+void Kern_White::_init() {
+  nParams = 1;
+  setKerName("white");
+  setParamName("Sigma_White", 0);
+  setInitPars();
+}
+void Kern_White::setParam(double val, unsigned int paramNo) {
+  if (paramNo != 0) { std::cout << "Requested parameter doesn't exist.\n"; exit(1); }
+  Sigma_White = val;
+}
+double Kern_White::getParam(unsigned int paramNo) const {
+  if (paramNo != 0) { std::cout << "Requested parameter doesn't exist.\n"; exit(1); }
+  return Sigma_White;
+}
+void Kern_White::computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const {  // Kernel.cpp:256-263
+  if (K.n_rows != X1.n_rows || K.n_cols != X2.n_rows) K.resize(X1.n_rows, X2.n_rows);
+  if (D2.n_rows != X1.n_rows || D2.n_cols != X2.n_rows) D2.resize(X1.n_rows, X2.n_rows);
+  D2.zeros();
+  K.zeros();
+  if (X1(0) == X2(0) && X1.n_rows == X2.n_rows)
+    for (size_t i = 0; i < X1.n_rows; i++) K(i, i) = Sigma_White;
+}
+
+// ---------------------------------------------------------------------------------------------
 // HybKerns
 // ---------------------------------------------------------------------------------------------
 void HybKerns::_init() { nParams = 0; setKerName("Hyb"); }
@@ -230,7 +314,14 @@ void HybKerns::computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const {  
     device_compute_k(e, bias, X1, X2, K, D2);  // ExpAns + Bias fused into one fill
     return;
   }
-  // any other composition: sum the children as the reference does
+  std::vector<int> kinds;
+  std::vector<double> pars;
+  double white;
+  if (gpak_extract_composition(this, kinds, pars, &bias, &white) && !kinds.empty()) {
+    device_compute_composition(this, X1, X2, K, D2);  // every child in the same fused fill
+    return;
+  }
+  // anything else: sum the children as the reference does
   K.resize(X1.n_rows, X2.n_rows);
   D2.resize(X1.n_rows, X2.n_rows);
   mat Kt(X1.n_rows, X2.n_rows), Dt(X1.n_rows, X2.n_rows);
@@ -263,6 +354,9 @@ Kernels *ReadKerFromFile(std::istream &in) {  // Kernel.cpp:1281-1307
   std::string name = line.substr(line.find("=") + 1);
   Kernels *k = nullptr;
   if (name == "Bias") k = new Kern_Bias();
+  else if (name == "white") k = new Kern_White();
+  else if (name == "RBF") k = new Kern_RBF();
+  else if (name == "Exp") k = new Kern_Exponential();
   else if (name == "ExpAns") k = new Kern_ExpAnisotropic();
   else if (name == "Hyb") k = new HybKerns();
   else { std::cout << "Unknown kernel type \n"; exit(1); }
@@ -283,6 +377,31 @@ bool gpak_extract_expans_bias(const Kernels *k, double expans[8], double *bias) 
     const Kern_Bias *b = dynamic_cast<const Kern_Bias *>(h->getKern(1));
     if (!b) return false;
     *bias = b->getParam(0);
+  }
+  return true;
+}
+
+bool gpak_extract_composition(const Kernels *k, std::vector<int> &kinds, std::vector<double> &pars, double *bias,
+                              double *white) {
+  kinds.clear(); pars.clear();
+  *bias = 0.0; *white = 0.0;
+  std::vector<const Kernels *> leaves;
+  if (const HybKerns *h = dynamic_cast<const HybKerns *>(k)) {
+    for (unsigned i = 0; i < h->getNumKerns(); i++) leaves.push_back(h->getKern(i));
+  } else {
+    leaves.push_back(k);
+  }
+  for (const Kernels *c : leaves) {
+    int kind = -1;
+    if (dynamic_cast<const Kern_ExpAnisotropic *>(c)) kind = GPAK_KERN_EXPANS;
+    else if (dynamic_cast<const Kern_Exponential *>(c)) kind = GPAK_KERN_EXP;
+    else if (dynamic_cast<const Kern_RBF *>(c)) kind = GPAK_KERN_RBF;
+    else if (dynamic_cast<const Kern_Bias *>(c)) { *bias += c->getParam(0); continue; }
+    else if (dynamic_cast<const Kern_White *>(c)) { *white += c->getParam(0); continue; }
+    else return false;
+    if (kinds.size() == 3) return false;  // the device composition holds three stationary terms
+    kinds.push_back(kind);
+    for (unsigned i = 0; i < c->getNPars(); i++) pars.push_back(c->getParam(i));
   }
   return true;
 }

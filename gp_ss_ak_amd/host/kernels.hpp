@@ -101,6 +101,61 @@ class Kern_Bias : public Kernels {
   double Sigma_Bias;
 };
 
+// isotropic exponential kernel over EuclDist (Kernel.cpp:550-700, 1343-1368): {Hayper_Euc_Exp, Sigma_Exp}
+class Kern_Exponential : public Kernels {
+ public:
+  Kern_Exponential() { _init(); }
+  explicit Kern_Exponential(unsigned int inDim) { _init(); setInputDim(inDim); }
+  explicit Kern_Exponential(const mat &X) { _init(); setInputDim((unsigned)X.n_cols); }
+  Kern_Exponential *clone() const override { return new Kern_Exponential(*this); }
+  void setInitPars() override { Hayper_Euc_Exp = 0.5; Sigma_Exp = 0.9; }   // Kernel.cpp:586-590
+  double Diag_Kernel(const mat &, unsigned int) const override { return Sigma_Exp * Sigma_Exp; }
+  void setParam(double val, unsigned int paramNo) override;
+  double getParam(unsigned int paramNo) const override;
+  void computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const override;
+
+ private:
+  void _init();
+  double Hayper_Euc_Exp, Sigma_Exp;
+};
+
+// isotropic squared-exponential kernel over EuclDist (Kernel.cpp:384-548):
+// {Hayper_Euc_RBF, inverseWidth_RBF, Sigma_RBF}
+class Kern_RBF : public Kernels {
+ public:
+  Kern_RBF() { _init(); }
+  explicit Kern_RBF(unsigned int inDim) { _init(); setInputDim(inDim); }
+  explicit Kern_RBF(const mat &X) { _init(); setInputDim((unsigned)X.n_cols); }
+  Kern_RBF *clone() const override { return new Kern_RBF(*this); }
+  void setInitPars() override { Hayper_Euc_RBF = 0.5; inverseWidth_RBF = 0.9; Sigma_RBF = 0.5; }  // Kernel.cpp:424-429
+  double Diag_Kernel(const mat &, unsigned int) const override { return Sigma_RBF * Sigma_RBF; }
+  void setParam(double val, unsigned int paramNo) override;
+  double getParam(unsigned int paramNo) const override;
+  void computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const override;
+
+ private:
+  void _init();
+  double Hayper_Euc_RBF, inverseWidth_RBF, Sigma_RBF;
+};
+
+// white noise on the diagonal of a set with itself (Kernel.cpp:180-270); Sigma_White is NOT squared
+class Kern_White : public Kernels {
+ public:
+  Kern_White() { _init(); }
+  explicit Kern_White(unsigned int inDim) { _init(); setInputDim(inDim); }
+  explicit Kern_White(const mat &X) { _init(); setInputDim((unsigned)X.n_cols); }
+  Kern_White *clone() const override { return new Kern_White(*this); }
+  void setInitPars() override { Sigma_White = 0.10; }                        // Kernel.cpp:214-217
+  double Diag_Kernel(const mat &, unsigned int) const override { return Sigma_White; }
+  void setParam(double val, unsigned int paramNo) override;
+  double getParam(unsigned int paramNo) const override;
+  void computeK(const mat &X1, const mat &X2, mat &K, mat &D2) const override;
+
+ private:
+  void _init();
+  double Sigma_White;
+};
+
 // additive container with flat parameter indexing (Kernel.h:158-253, Kernel.cpp:55-169)
 class HybKerns : public Kernels {
  public:
@@ -134,6 +189,9 @@ Kernels *ReadKerFromFile(std::istream &in);
 // What the hot path needs from a kernel object: the {ExpAns, Bias} parameters.  Returns false
 // when the kernel is not an ExpAns(+Bias) composition (those run on the reference's CPU path).
 bool gpak_extract_expans_bias(const Kernels *k, double expans[8], double *bias);
+// General form: the stationary children (kinds GPAK_KERN_*, parameters concatenated), Bias and White.
+bool gpak_extract_composition(const Kernels *k, std::vector<int> &kinds, std::vector<double> &pars, double *bias,
+                              double *white);
 
 // process-wide scratch device context for kernels evaluated outside a GP_utils
 struct gpak_ctx;

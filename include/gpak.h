@@ -76,6 +76,17 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
  * values are bit-identical to the previous call. */
 int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2, int dist_mode);
 
+/* General additive composition (HybKerns of other children, Kernel.cpp:140-154): up to 3 stationary
+ * terms + Kern_Bias + Kern_White.  kinds[t] and the concatenated parameter list in the reference's
+ * own order: GPAK_KERN_EXPANS 8 values (Kernel.cpp:737-761), GPAK_KERN_EXP {Hayper_Euc_Exp, Sigma_Exp}
+ * (Kernel.cpp:576-600), GPAK_KERN_RBF {Hayper_Euc_RBF, inverseWidth_RBF, Sigma_RBF} (Kernel.cpp:411-428).
+ * Gram, factor, alpha, nlZ and prediction work for any composition; gpak_grad only for ExpAns(+Bias). */
+#define GPAK_KERN_EXPANS 0
+#define GPAK_KERN_EXP    1
+#define GPAK_KERN_RBF    2
+int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *pars, double bias, double white,
+                    double sn2, int dist_mode);
+
 #define GPAK_OPT_MEMOISE   1  /* value-based dirty tracking instead of always-invalidate   */
 #define GPAK_OPT_NB_OUTER  2  /* outer Cholesky block width (multiple of 128)              */
 #define GPAK_OPT_PROFILE   3  /* 1: bracket each trailing-update launch with hip events    */

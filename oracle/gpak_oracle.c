@@ -186,6 +186,76 @@ void orc_gram(const double *X1, int n, const double *X2, int m, int d, const dou
 
 double orc_kdiag(const double *expans, double bias) { return expans[6] * expans[6] + bias; }
 
+/* EuclDist, Kernel.cpp:1343-1368 with mlA :1437-1441: AX = X * hyp^-2;
+ * D2 = sum(AX1 % X1,1) 1' + 1 sum(AX2 % X2,1)' - 2 X1 AX2', pooled-mean centred, clamped */
+void orc_eucldist(const double *X1, int n, const double *X2, int m, int d, double hyp, int mode, double *D2) {
+  double mu[4];
+  for (int j = 0; j < d; j++) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; i++) s1 += X1[i + (size_t)j * n];
+    for (int i = 0; i < m; i++) s2 += X2[i + (size_t)j * m];
+    double mX1 = (double)n / (n + m) * s1 / n;
+    mu[j] = (double)m / (n + m) * s2 / m + mX1;
+  }
+  const double sc = exp(-2.0 * log(hyp));
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < n; i++) {
+      double v;
+      if (mode == ORC_DIST_EXPANSION) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int k = 0; k < d; k++) {
+          double x1 = X1[i + (size_t)k * n] - mu[k], x2 = X2[j + (size_t)k * m] - mu[k];
+          a += sc * x1 * x1; b += sc * x2 * x2; c += x1 * (sc * x2);
+        }
+        v = a + b - 2.0 * c;
+        if (v < 0) v = 0.0;
+      } else {
+        v = 0.0;
+        for (int k = 0; k < d; k++) {
+          double t = (X1[i + (size_t)k * n] - X2[j + (size_t)k * m]) / hyp;
+          v += t * t;
+        }
+      }
+      D2[i + (size_t)j * n] = v;
+    }
+}
+
+/* HybKerns::computeK over arbitrary children (Kernel.cpp:140-154): kinds 0 ExpAns (8 pars,
+ * :856-882), 1 Exp (2 pars {hyp, sigma}), 2 RBF (3 pars {hyp, iw, sigma}, :482-488); plus
+ * Kern_Bias (:362-367) and Kern_White (:256-263: diagonal only when X1(0)==X2(0) and n==m). */
+void orc_gram_hyb(const double *X1, int n, const double *X2, int m, int d, int nterms, const int *kinds,
+                  const double *pars, double bias, double white, int mode, double *K, double *D2sum) {
+  size_t tot = (size_t)n * m;
+  double *D = (double *)malloc(sizeof(double) * tot);
+  for (size_t t = 0; t < tot; t++) { K[t] = bias; if (D2sum) D2sum[t] = 0.0; }
+  const double *p = pars;
+  for (int t = 0; t < nterms; t++) {
+    if (kinds[t] == 0) {
+      double par[7];
+      pack_paramker(p, par);
+      orc_mahadist(X1, n, X2, m, d, par, mode, D);
+      double v2 = p[6] * p[6];
+      for (size_t e = 0; e < tot; e++) K[e] += v2 * exp(-1.0 * sqrt(D[e]));
+      p += 8;
+    } else if (kinds[t] == 1) {
+      orc_eucldist(X1, n, X2, m, d, p[0], mode, D);
+      double v2 = p[1] * p[1];
+      for (size_t e = 0; e < tot; e++) K[e] += v2 * exp(-1.0 * sqrt(D[e]));
+      p += 2;
+    } else {
+      orc_eucldist(X1, n, X2, m, d, p[0], mode, D);
+      double v2 = p[2] * p[2];
+      for (size_t e = 0; e < tot; e++) K[e] += exp(-0.5 * p[1] * D[e]) * v2;
+      p += 3;
+    }
+    if (D2sum) for (size_t e = 0; e < tot; e++) D2sum[e] += D[e];
+  }
+  if (white != 0.0 && X1[0] == X2[0] && n == m)
+    for (int i = 0; i < n; i++) K[i + (size_t)i * n] += white;
+  free(D);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Dense linear algebra (in-repo fallback when no LAPACK is bound)           */
 /* ------------------------------------------------------------------------- */

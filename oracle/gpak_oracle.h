@@ -53,6 +53,12 @@ void orc_mahadist(const double *X1, int n, const double *X2, int m, int d,
 void orc_gram(const double *X1, int n, const double *X2, int m, int d,
               const double *expans, double bias, int mode, double *K, double *D2);
 
+/* HybKerns::computeK over arbitrary children: kinds[t] 0 ExpAns / 1 Exp / 2 RBF with their parameters
+ * concatenated in the reference's order, Kern_Bias, Kern_White (Kernel.cpp:140-154, 256-263, 482-488,
+ * 1343-1368).  D2sum (sum of the children's D2) may be NULL. */
+void orc_gram_hyb(const double *X1, int n, const double *X2, int m, int d, int nterms, const int *kinds,
+                  const double *pars, double bias, double white, int mode, double *K, double *D2sum);
+
 /* diag_Compute of the composite kernel (Kernel.cpp:780-783, 328-332, 127-136) */
 double orc_kdiag(const double *expans, double bias);
 

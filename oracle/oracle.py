@@ -105,6 +105,20 @@ def gram(X1, X2, expans, bias, mode=DIST_EXPANSION, want_d2=False):
     return (K, D2) if want_d2 else K
 
 
+def gram_hyb(X1, X2, terms, bias, white, mode=DIST_EXPANSION, want_d2=False):
+    """terms = [(kind, params)], kind 0 ExpAns / 1 Exp / 2 RBF."""
+    X1, X2 = _f(X1), _f(X2)
+    n, d = X1.shape
+    m = X2.shape[0]
+    kinds = (C.c_int * len(terms))(*[int(k) for k, _ in terms])
+    pars = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64) for _, p in terms]))
+    K = np.zeros((n, m), order="F")
+    D2 = np.zeros((n, m), order="F") if want_d2 else None
+    lib().orc_gram_hyb(_p(X1), C.c_int(n), _p(X2), C.c_int(m), C.c_int(d), C.c_int(len(terms)), kinds, _p(pars),
+                       C.c_double(bias), C.c_double(white), C.c_int(mode), _p(K), _p(D2) if want_d2 else None)
+    return (K, D2) if want_d2 else K
+
+
 def kdiag(expans, bias):
     e = np.ascontiguousarray(expans, dtype=np.float64)
     return lib().orc_kdiag(_p(e), C.c_double(bias))

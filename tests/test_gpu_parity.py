@@ -134,3 +134,39 @@ def test_fp32_prediction_context(orc):
     assert rel(mean, mo) <= 1e-8
     assert rel(var, vo) <= 2e-4
     g32.close()
+
+
+@pytest.mark.parametrize("mode", [gpak.DIST_DIRECT, gpak.DIST_EXPANSION])
+def test_other_kernel_compositions(gp, orc, mode):
+    """f-4: HybKerns{ExpAns, Exp, RBF} + Bias + White through gpak_set_kernel: Gram, nlZ, alpha, prediction.
+    (the reference-style gradient exists for ExpAns(+Bias) only)"""
+    import scipy.linalg as sl
+    N, M = 700, 40
+    X, y = synth.drillholes(N)
+    Xt = synth.test_points(M)
+    white = 0.10
+    terms = [(gpak.KERN_EXPANS, E), (gpak.KERN_EXP, [0.5, 0.9]), (gpak.KERN_RBF, [0.5, 0.9, 0.5])]
+    gp.set_train(X, y)
+    gp.set_kernel(terms, BIAS, white, SN2, mode)
+    tolk = 1e-13 if mode == gpak.DIST_DIRECT else 2e-7
+    K, D2 = gp.gram(want_d2=True)
+    Ko, D2o = orc.gram_hyb(X, X, terms, BIAS, white, mode, want_d2=True)
+    assert rel(K, Ko) <= tolk and np.abs(D2 - D2o).max() <= 1e-12
+    Kc = gp.compute_k(X, Xt)
+    assert rel(Kc, orc.gram_hyb(X, Xt, terms, BIAS, white, mode)) <= tolk
+    info, alpha_o, Lo = orc.nlz_lean(Ko, y, SN2)
+    tol = 1e-9 if mode == gpak.DIST_DIRECT else 1e-6
+    assert abs(gp.logLikelihood() - info.nlz) <= tol * abs(info.nlz)
+    assert rel(gp.solve_alpha(), alpha_o) <= (1e-8 if mode == gpak.DIST_DIRECT else 1e-5)
+    mean, var = gp.posteriorMeanVar(Xt)
+    kX = orc.gram_hyb(X, Xt, terms, BIAS, white, mode)
+    cf = sl.cho_factor(Ko + SN2 * np.eye(N), lower=True)
+    kD = E[6] ** 2 + 0.9 ** 2 + 0.5 ** 2 + BIAS + white      # HybKerns::diag_Compute
+    mo = kX.T @ alpha_o
+    vo = np.maximum(kD - np.einsum("ij,ij->j", kX, sl.cho_solve(cf, kX)), 0) + SN2
+    tp = 1e-8 if mode == gpak.DIST_DIRECT else 1e-5
+    assert rel(mean, mo) <= tp and rel(var, vo) <= tp
+    with pytest.raises(gpak.GpakError) as ei:
+        gp.GradLL()
+    assert ei.value.status == gpak.ENOTIMPL
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)   # back to the default composition for later tests

@@ -124,6 +124,13 @@ def test_class_surface_matches_oracle(orc, tmp_path):
     info2, _, _ = orc.nlz_refseq(K, y, 0.05)
     assert abs(r["nlz_sn2_005"] - info2.nlz) <= 1e-9 * abs(info2.nlz)
     assert r["chol_fail_is_nan"] is True
+    # f-4: HybKerns{ExpAns, RBF, Exp, Bias, White} with the reference defaults of every child
+    terms = [(0, E), (2, [0.5, 0.9, 0.5]), (1, [0.5, 0.9])]
+    K5 = orc.gram_hyb(X, X, terms, 0.2, 0.10, orc.DIST_DIRECT)
+    info5, _, _ = orc.nlz_lean(K5, y, 0.016)
+    assert r["hyb5_npars"] == 8 + 3 + 2 + 1 + 1 + 1
+    assert abs(r["hyb5_K_sum"] - K5.sum()) <= 1e-12 * abs(K5.sum()) and abs(r["hyb5_K00"] - K5[0, 0]) <= 1e-14
+    assert abs(r["hyb5_nlz"] - info5.nlz) <= 1e-9 * abs(info5.nlz)
     assert np.allclose(r["params_reloaded"], [float(f"{v:.6g}") for v in list(E) + [0.2, 0.016]], rtol=0, atol=0)
 
 

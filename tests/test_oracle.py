@@ -288,3 +288,25 @@ def test_synthetic_generator_is_deterministic_and_standardised():
     assert np.abs(Xs * params[1:, 1] + params[1:, 0] - Xr).max() <= 1e-9
     assert np.abs(ys * params[0, 1] + params[0, 0] - yr).max() <= 1e-12
     assert len({params[1, 0], params[2, 0], params[3, 0]}) == 1      # geometry preserved
+
+
+def test_other_kernels_match_numpy(orc):
+    """f-4: Kern_Exponential / Kern_RBF over EuclDist, Kern_White, and their sum with ExpAns + Bias."""
+    X, _ = synth.drillholes(90)
+    Xt = synth.test_points(11)
+    hyp_e, sig_e, hyp_r, iw_r, sig_r, white = 0.5, 0.9, 0.5, 0.9, 0.5, 0.10   # Kernel.cpp:586-590, 424-429, 214-217
+    terms = [(0, E), (1, [hyp_e, sig_e]), (2, [hyp_r, iw_r, sig_r])]
+    d = X[:, None, :] - X[None, :, :]
+    r2 = (d ** 2).sum(-1)
+    Kx, _ = np_gram(X, X, E, 0.0)
+    want = Kx + sig_e ** 2 * np.exp(-np.sqrt(r2 / hyp_e ** 2)) + sig_r ** 2 * np.exp(-0.5 * iw_r * r2 / hyp_r ** 2) \
+        + BIAS + white * np.eye(90)
+    for mode, tol in ((orc.DIST_DIRECT, 1e-13), (orc.DIST_EXPANSION, 5e-7)):
+        K = orc.gram_hyb(X, X, terms, BIAS, white, mode)
+        assert np.abs(K - want).max() <= tol
+    # cross block: no white noise (X1(0) != X2(0)), Kernel.cpp:260-262
+    dc = X[:, None, :] - Xt[None, :, :]
+    rc = (dc ** 2).sum(-1)
+    Kc, _ = np_gram(X, Xt, E, 0.0)
+    wantc = Kc + sig_e ** 2 * np.exp(-np.sqrt(rc / hyp_e ** 2)) + sig_r ** 2 * np.exp(-0.5 * iw_r * rc / hyp_r ** 2) + BIAS
+    assert np.abs(orc.gram_hyb(X, Xt, terms, BIAS, white, orc.DIST_DIRECT) - wantc).max() <= 1e-13
