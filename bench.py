@@ -202,7 +202,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=32768)
+    # --size rather than only --n: torch.distributed.run abbreviation-matches "--n" against its own options
+    ap.add_argument("--n", "--size", dest="n", type=int, default=32768)
     ap.add_argument("--dist", choices=["direct", "expansion"], default="direct")
     ap.add_argument("--nb-outer", type=int, default=0)
     ap.add_argument("--cpu-n", type=int, default=8192, help="sample size of the CPU baseline")

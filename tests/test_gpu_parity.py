@@ -170,3 +170,42 @@ def test_other_kernel_compositions(gp, orc, mode):
         gp.GradLL()
     assert ei.value.status == gpak.ENOTIMPL
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)   # back to the default composition for later tests
+
+
+def test_full_size_properties_n32768(gp):
+    """BASELINE.json's full size (N=32768, fp64): no CPU oracle finishes here in seconds, so the
+    step is checked through identities that hold at any size:
+      (K + sn2 I) alpha = y   =>   y - f = sn2 alpha  with f = K alpha computed by the device;
+      quad = alpha'(f/2),  sumlp = -|y-f|^2/(2 sn2) - N/2 log(2 pi sn2);
+      solve_chol is linear and inverts B = I + K/sn2 (checked on alpha itself);
+      the step is deterministic (bit-identical when repeated)."""
+    N = 32768
+    X, y = synth.drillholes(N)
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    nlz1 = gp.logLikelihood()
+    alpha = gp.solve_alpha()
+    quad, sumlp, logdet = gp.nlz_terms()
+    assert np.isfinite(nlz1) and nlz1 == quad - sumlp + logdet
+    # |y - f|^2 from sumlp must equal sn2^2 |alpha|^2
+    res2 = -2.0 * SN2 * (sumlp + 0.5 * N * math.log(2 * math.pi * SN2))
+    assert abs(res2 - SN2 ** 2 * (alpha @ alpha)) <= 1e-7 * res2
+    # quad = 1/2 alpha'(y - sn2 alpha)
+    assert abs(quad - 0.5 * alpha @ (y - SN2 * alpha)) <= 1e-8 * abs(quad)
+    # B^-1 (y/sn2) = alpha, and linearity of the two triangular solves
+    r = np.column_stack([y / SN2, np.ones(N), 2.0 * y / SN2 - 3.0 * np.ones(N)])
+    S = gp.solve_chol(r)
+    assert rel(S[:, 0], alpha) <= 1e-12
+    assert rel(S[:, 2], 2.0 * S[:, 0] - 3.0 * S[:, 1]) <= 1e-10
+    # log det B lies between N log(1) and N log(1 + kdiag*N/sn2) and the diagonal of L is positive
+    assert 0.0 < logdet < 0.5 * N * math.log(1.0 + (E[6] ** 2 + BIAS) * N / SN2)
+    # deterministic
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    assert gp.logLikelihood() == nlz1 and np.array_equal(gp.solve_alpha(), alpha)
+    # prediction at training points: the latent variance is below the prior and above zero, the mean
+    # reproduces y - sn2 alpha (f at the training points)
+    idx = np.arange(0, N, 997)
+    mean, var = gp.posteriorMeanVar(X[idx])
+    assert rel(mean, (y - SN2 * alpha)[idx]) <= 1e-7
+    assert np.all(var - SN2 >= 0) and np.all(var - SN2 < E[6] ** 2 + BIAS)
+    gp.set_train(X[:64], y[:64])   # release the 8.6 GB buffer for the following tests

@@ -96,3 +96,24 @@ def test_hip_engine_expansion_mode_and_chol_fail(orc):
     assert abs(res[0]["nlz"] - info.nlz) <= 1e-6 * abs(info.nlz)    # expansion mode: cancellation noise
     res = run_world(2, 900, 256, engine="hip", sn2=-0.5)
     assert all(r["nlz"] != r["nlz"] for r in res)
+
+
+@pytest.mark.gpu
+def test_bench_distributed_entry_point_over_rccl():
+    """bench.py --gpus path exactly as the driver launches it (torch.distributed.run, backend nccl = RCCL),
+    with the one rank this box has; the step must agree with the single-context path."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, GPAK_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps",
+           "2", "--warmup", "1", "--size", "4096", "--no-cpu"]
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["unit"] == "steps/s" and d["value"] > 0 and "roofline" in d
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--n",
+                             "4096", "--no-cpu"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert single.returncode == 0, single.stderr.decode()[-2000:]
+    s = json.loads([l for l in single.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
