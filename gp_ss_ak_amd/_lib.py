@@ -14,7 +14,7 @@ SYMBOLS = [
     "gpak_create", "gpak_destroy", "gpak_last_error", "gpak_global_error", "gpak_set_train",
     "gpak_set_params", "gpak_set_kernel", "gpak_set_option", "gpak_gram", "gpak_compute_k", "gpak_factor",
     "gpak_get_chol_upper", "gpak_failed_column", "gpak_solve_alpha", "gpak_solve_chol", "gpak_nlz",
-    "gpak_nlz_terms", "gpak_predict", "gpak_grad", "gpak_timing", "gpak_calibrate",
+    "gpak_nlz_terms", "gpak_predict", "gpak_grad", "gpak_grad_hyb", "gpak_timing", "gpak_calibrate",
 ]
 
 
@@ -65,6 +65,7 @@ def load():
     lib.gpak_nlz_terms.argtypes = [vp, dp, dp, dp]
     lib.gpak_predict.argtypes = [vp, dp, C.c_long, C.c_int, dp, dp, C.c_int]
     lib.gpak_grad.argtypes = [vp, dp]
+    lib.gpak_grad_hyb.argtypes = [vp, dp, C.c_int]
     lib.gpak_timing.argtypes = [vp, C.POINTER(PhaseTimes)]
     lib.gpak_calibrate.argtypes = [vp, dp, dp]
     _lib = lib

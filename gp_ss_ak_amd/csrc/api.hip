@@ -11,7 +11,7 @@
 int gpak_calibrate_impl(gpak_ctx *ctx, double *scratch, size_t scratch_bytes, double *tflops, double *gbs);
 int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var);
 int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k);
-int gpak_grad_impl(gpak_ctx *ctx, double *g);
+int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng);
 
 static std::string g_global_err;
 
@@ -217,6 +217,7 @@ int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2
   ctx->bias = bias; ctx->sn2 = sn2; ctx->dist_mode = dist_mode;
   ctx->have_params = true;
   ctx->expans_only = true;
+  ctx->kinds[0] = GPAK_KERN_EXPANS;
   ctx->kp.nterms = 1;
   gpak_build_siginv(expans, ctx->kp.term[0].A);
   ctx->kp.term[0].var2 = expans[6] * expans[6];
@@ -265,6 +266,7 @@ int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *p
       p += 3;
     } else { ctx->err = "unknown kernel kind"; return GPAK_EINVAL; }
     kdiag += T.var2;
+    ctx->kinds[t] = kinds[t];
   }
   kp.bias = bias; kp.white = white; kp.mode = dist_mode;
   ctx->kp = kp;
@@ -544,7 +546,14 @@ int gpak_grad(gpak_ctx *ctx, double *g) {
   if (!ctx->expans_only) { ctx->err = "gpak_grad handles the ExpAns(+Bias) composition only"; return GPAK_ENOTIMPL; }
   int rc = ensure_nlz(ctx);  // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
   if (rc) return rc;
-  return gpak_grad_impl(ctx, g);
+  return gpak_grad_impl(ctx, g, 10);
+}
+
+int gpak_grad_hyb(gpak_ctx *ctx, double *g, int ng) {
+  if (!ctx || !g) return GPAK_EINVAL;
+  int rc = ensure_nlz(ctx);
+  if (rc) return rc;
+  return gpak_grad_impl(ctx, g, ng);
 }
 
 int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out) {

@@ -58,7 +58,8 @@ struct gpak_ctx {
   // parameters
   bool have_params = false;
   double expans[8] = {0};   // ExpAns parameters when the kernel is the reference's default composition
-  bool expans_only = true;  // kernel == ExpAns(+Bias): the only composition gpak_grad handles
+  bool expans_only = true;  // kernel == ExpAns(+Bias): the composition of the fixed-length gpak_grad
+  int kinds[GPAK_MAX_TERMS] = {0, 0, 0};  // GPAK_KERN_* of each stationary term
   double bias = 0, sn2 = 0;
   int dist_mode = GPAK_DIST_DIRECT;
   KernParams kp;

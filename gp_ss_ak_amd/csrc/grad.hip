@@ -14,6 +14,7 @@
 //   3. ONE fused pass over the pairs i >= j that recomputes K_ij from the coordinates and
 //      accumulates the nine sums the ten gradient entries are made of.
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "gpak_internal.h"
@@ -21,13 +22,15 @@
 #define PB 128
 #define GT_ROWS 128
 #define GT_COLS 64
-#define NSUM 9
+#define NSUM 15  // 9 shared/ExpAns sums + 2 per stationary term for the Exp / RBF children
 
 struct GradConsts {
   double M[6][6];   // S % S_p, symmetric 3x3 stored as {00,01,02,11,12,22}, p = 0..5
   double m2[6][3];  // 2 * column sums of M_p : a_i^(p) = sum_k x_ik^2 m2[p][k]
   double var2, bias, sn2;
   int mode;
+  int te;           // index of the ExpAns term (-1: none)
+  int kinds[GPAK_MAX_TERMS];
 };
 
 __global__ void gpak_identity_f64(double *W, long ld, int n) {
@@ -39,18 +42,23 @@ __global__ void gpak_identity_f64(double *W, long ld, int n) {
 }
 
 // pair pass over the lower triangle; block partials: part[block][NSUM]
+//   [0..5] sum Rm * Di2^(p)   [6] sum QW * exp(-sqrt(D_expans))   [7] sum Q * K   [8] trace(QW)
+//   [9+2t], [10+2t]  the two sums of stationary term t when it is an Exp or RBF child; those
+//   children work on GP_utils' member D2 = the SUM of the children's D2 (Kernel.cpp:151, 491-540, 644-693)
+#define PARRG(base, cap, t, c) ((base) + (size_t)(4 * (t) + (c)) * (cap))
 __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
-    const double *__restrict__ u0, const double *__restrict__ u1, const double *__restrict__ u2,
-    const double *__restrict__ us, const double *__restrict__ x0, const double *__restrict__ x1,
+    const double *__restrict__ U, int cap, const double *__restrict__ x0, const double *__restrict__ x1,
     const double *__restrict__ x2, const double *__restrict__ alpha, const double *__restrict__ Binv, long ld,
-    int N, GradConsts gc, double *__restrict__ part) {
+    int N, KernParams kp, GradConsts gc, double *__restrict__ part) {
   const int row0 = blockIdx.x * GT_ROWS, col0 = blockIdx.y * GT_COLS;
   const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-  __shared__ double cq[5][GT_COLS];        // u0,u1,u2,|u|^2, alpha of the column points
-  __shared__ double cm[6][3][GT_COLS];     // M_p x_j
-  __shared__ double ca[6][GT_COLS];        // a_j^(p)
+  __shared__ double cq[GPAK_MAX_TERMS][4][GT_COLS];  // transformed column points, per term
+  __shared__ double cal[GT_COLS];                    // alpha of the column points
+  __shared__ double cm[6][3][GT_COLS];               // M_p x_j
+  __shared__ double ca[6][GT_COLS];                  // a_j^(p)
   __shared__ double red[4][NSUM];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int nterms = kp.nterms, te = gc.te;
   double acc[NSUM];
 #pragma unroll
   for (int k = 0; k < NSUM; k++) acc[k] = 0.0;
@@ -58,8 +66,10 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
     if (t < GT_COLS) {
       const int j = col0 + t;
       const bool ok = j < N;
-      cq[0][t] = ok ? u0[j] : 0.0; cq[1][t] = ok ? u1[j] : 0.0; cq[2][t] = ok ? u2[j] : 0.0;
-      cq[3][t] = ok ? us[j] : 0.0; cq[4][t] = ok ? alpha[j] : 0.0;
+      for (int m = 0; m < nterms; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) cq[m][c][t] = ok ? PARRG(U, cap, m, c)[j] : 0.0;
+      cal[t] = ok ? alpha[j] : 0.0;
       const double a = ok ? x0[j] : 0.0, b = ok ? x1[j] : 0.0, c = ok ? x2[j] : 0.0;
 #pragma unroll
       for (int p = 0; p < 6; p++) {
@@ -72,13 +82,14 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
     }
     __syncthreads();
     const int r = row0 + 2 * lane;
-    double pu[2][4], px[2][3], pa[2][6], pal[2];
+    double pu[2][GPAK_MAX_TERMS][4], px[2][3], pa[2][6], pal[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int i = r + h;
       const bool ok = i < N;
-      pu[h][0] = ok ? u0[i] : 0.0; pu[h][1] = ok ? u1[i] : 0.0; pu[h][2] = ok ? u2[i] : 0.0;
-      pu[h][3] = ok ? us[i] : 0.0;
+      for (int m = 0; m < nterms; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) pu[h][m][c] = ok ? PARRG(U, cap, m, c)[i] : 0.0;
       px[h][0] = ok ? x0[i] : 0.0; px[h][1] = ok ? x1[i] : 0.0; px[h][2] = ok ? x2[i] : 0.0;
       pal[h] = ok ? alpha[i] : 0.0;
 #pragma unroll
@@ -96,29 +107,54 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
         if (i >= N || i < j) continue;
         const double q = h ? q2.y : q2.x;
         const double wgt = (i == j) ? 1.0 : 2.0;  // every summand is symmetric in (i, j)
-        double d2;
-        if (gc.mode == GPAK_DIST_DIRECT) {
-          const double a = pu[h][0] - cq[0][jl], b = pu[h][1] - cq[1][jl], cc = pu[h][2] - cq[2][jl];
-          d2 = a * a + b * b + cc * cc;
-        } else {
-          const double dot = pu[h][0] * cq[0][jl] + pu[h][1] * cq[1][jl] + pu[h][2] * cq[2][jl];
-          d2 = pu[h][3] + cq[3][jl] - 2.0 * dot;
-          d2 = d2 < 0.0 ? 0.0 : d2;
-        }
-        const double sd = sqrt(d2);                       // Kernel.cpp:1178
-        const double ek = exp(-1.0 * sd);                 // KD2, :1176
-        const double qw = q * (1.0 / gc.sn2) - pal[h] * cq[4][jl];   // dhyp, GP_Utils.cpp:1168
-        double dk = (sd == 0.0 || i == j) ? 0.0 : ek * (-0.5 / sd);  // :1179-1184
-        const double rm = gc.var2 * qw * dk;              // R = Qs % dk, :927, :1185
+        double d2m[GPAK_MAX_TERMS], d2s = 0.0, kfull = gc.bias;
 #pragma unroll
-        for (int p = 0; p < 6; p++) {
-          const double xmx = px[h][0] * cm[p][0][jl] + px[h][1] * cm[p][1][jl] + px[h][2] * cm[p][2][jl];
-          const double di2 = pa[h][p] + ca[p][jl] - 4.0 * xmx;   // Di2, :1192-1194
-          acc[p] = fma(wgt * rm, di2, acc[p]);
+        for (int m = 0; m < GPAK_MAX_TERMS; m++) {
+          if (m >= nterms) break;
+          double d2;
+          if (gc.mode == GPAK_DIST_DIRECT) {
+            const double a = pu[h][m][0] - cq[m][0][jl], b = pu[h][m][1] - cq[m][1][jl], cc = pu[h][m][2] - cq[m][2][jl];
+            d2 = a * a + b * b + cc * cc;
+          } else {
+            const double dot = pu[h][m][0] * cq[m][0][jl] + pu[h][m][1] * cq[m][1][jl] + pu[h][m][2] * cq[m][2][jl];
+            d2 = pu[h][m][3] + cq[m][3][jl] - 2.0 * dot;
+            d2 = d2 < 0.0 ? 0.0 : d2;
+          }
+          d2m[m] = d2;
+          d2s += d2;
+          kfull += kp.term[m].var2 * (kp.term[m].profile == GPAK_PROFILE_RBF ? exp(-0.5 * kp.term[m].iw * d2)
+                                                                            : exp(-1.0 * sqrt(d2)));
         }
-        acc[6] = fma(wgt * qw, ek, acc[6]);                                  // :1239-1241
-        acc[7] = fma(wgt * q, gc.var2 * ek + gc.bias, acc[7]);               // sum(Q % K), GP_Utils.cpp:1206
-        if (i == j) acc[8] += qw;                                            // trace(QW), Kernel.cpp:370-377
+        const double qw = q * (1.0 / gc.sn2) - pal[h] * cal[jl];   // dhyp, GP_Utils.cpp:1168
+        acc[7] = fma(wgt * q, kfull, acc[7]);                       // sum(Q % K), GP_Utils.cpp:1206
+        if (i == j) acc[8] += qw;                                   // trace(QW), Kernel.cpp:370-377
+        if (te >= 0) {
+          const double sd = sqrt(d2m[te]);                          // Kernel.cpp:1178
+          const double ek = exp(-1.0 * sd);                         // KD2, :1176
+          const double dk = (sd == 0.0 || i == j) ? 0.0 : ek * (-0.5 / sd);  // :1179-1184
+          const double rm = gc.var2 * qw * dk;                      // R = Qs % dk, :927, :1185
+#pragma unroll
+          for (int p = 0; p < 6; p++) {
+            const double xmx = px[h][0] * cm[p][0][jl] + px[h][1] * cm[p][1][jl] + px[h][2] * cm[p][2][jl];
+            const double di2 = pa[h][p] + ca[p][jl] - 4.0 * xmx;    // Di2, :1192-1194
+            acc[p] = fma(wgt * rm, di2, acc[p]);
+          }
+          acc[6] = fma(wgt * qw, ek, acc[6]);                       // :1239-1241
+        }
+#pragma unroll
+        for (int m = 0; m < GPAK_MAX_TERMS; m++) {
+          if (m >= nterms) break;
+          if (gc.kinds[m] == GPAK_KERN_EXP) {                       // Kernel.cpp:644-693 on the summed D2
+            const double sd = sqrt(d2s), kd = exp(-1.0 * sd);
+            const double dk = (sd == 0.0 || i == j) ? 0.0 : kd * (-0.5 / sd);
+            acc[9 + 2 * m] = fma(wgt * qw * dk, d2s, acc[9 + 2 * m]);
+            acc[10 + 2 * m] = fma(wgt * qw * kd, kd, acc[10 + 2 * m]);
+          } else if (gc.kinds[m] == GPAK_KERN_RBF) {                // Kernel.cpp:491-540 on the summed D2
+            const double kd = exp(-0.5 * kp.term[m].iw * d2s);
+            acc[9 + 2 * m] = fma(wgt * qw * kd, d2s, acc[9 + 2 * m]);
+            acc[10 + 2 * m] = fma(wgt * qw, kd, acc[10 + 2 * m]);
+          }
+        }
       }
     }
   }
@@ -227,11 +263,27 @@ static void build_grad_consts(const double *e, GradConsts &gc) {
   }
 }
 
-int gpak_grad_impl(gpak_ctx *ctx, double *g) {
+// kinds of the current composition (set by gpak_set_params / gpak_set_kernel)
+int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng) {
   GPAK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const int N = ctx->N, Np = ctx->Np, T = Np / PB;
+  const int N = ctx->N, Np = ctx->Np;
   const long ld = ctx->ld;
+  // expected length: children in order (8 / 2 / 3), bias, sn2
+  int need = 2, te = -1;
+  for (int t = 0; t < ctx->kp.nterms; t++) {
+    need += ctx->kinds[t] == GPAK_KERN_EXPANS ? 8 : ctx->kinds[t] == GPAK_KERN_EXP ? 2 : 3;
+    if (ctx->kinds[t] == GPAK_KERN_EXPANS) {
+      if (te >= 0) { ctx->err = "gpak_grad: at most one ExpAns child"; return GPAK_ENOTIMPL; }
+      te = t;
+    }
+  }
+  if (ng != need) { ctx->err = "gpak_grad: gradient vector has the wrong length"; return GPAK_EINVAL; }
+  if (ctx->kp.white != 0.0) {
+    // Kern_White has no getGradients upstream (Kernel.h:257-283: the base method calls itself)
+    ctx->err = "gpak_grad: compositions with a White child have no gradient in the reference either";
+    return GPAK_ENOTIMPL;
+  }
   if (!ctx->dG) {
     if (hipMalloc(&ctx->dG, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
         hipMalloc(&ctx->dBinv, sizeof(double) * (size_t)ld * Np) != hipSuccess) {
@@ -268,11 +320,14 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g) {
                           ctx->dM + (J + W) + (size_t)J * ld, ld, 1.0, G + (size_t)(J + W) * ld, ld, 0, 0, false, false);
   }
   // 2. B^-1 = G G^T (lower tiles); G[i,k] = 0 for k < i, so the k-loop starts at the row tile
-  gpak_launch_gemm_nt(st, T, T, Np, 1.0, G, ld, G, ld, 0.0, ctx->dBinv, ld, 0, 0, true, true, true);
+  gpak_launch_gemm_nt(st, Np / PB, Np / PB, Np, 1.0, G, ld, G, ld, 0.0, ctx->dBinv, ld, 0, 0, true, true, true);
   // 3. fused pair pass
   GradConsts gc;
-  build_grad_consts(ctx->expans, gc);
-  gc.var2 = ctx->kp.term[0].var2; gc.bias = ctx->bias; gc.sn2 = ctx->sn2; gc.mode = ctx->dist_mode;
+  memset(&gc, 0, sizeof(gc));
+  if (te >= 0) build_grad_consts(ctx->expans, gc);
+  gc.var2 = te >= 0 ? ctx->kp.term[te].var2 : 0.0;
+  gc.bias = ctx->bias; gc.sn2 = ctx->sn2; gc.mode = ctx->dist_mode; gc.te = te;
+  for (int t = 0; t < GPAK_MAX_TERMS; t++) gc.kinds[t] = t < ctx->kp.nterms ? ctx->kinds[t] : -1;
   dim3 grid(Np / GT_ROWS, Np / GT_COLS);
   const size_t nblocks = (size_t)grid.x * grid.y;
   if (ctx->gpart_elems < nblocks * NSUM) {
@@ -286,9 +341,8 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g) {
   }
   int rc = gpak_ensure_U(ctx);
   if (rc) return rc;
-  hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, ctx->U.base, ctx->U.base + ctx->U.cap, ctx->U.base + 2 * (size_t)ctx->U.cap, ctx->U.base + 3 * (size_t)ctx->U.cap,
-                     ctx->dX, ctx->dX + Np, ctx->dX + 2 * (size_t)Np, ctx->dAlpha, ctx->dBinv, ld, N, gc,
-                     ctx->dGpart);
+  hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, ctx->U.base, ctx->U.cap, ctx->dX, ctx->dX + Np,
+                     ctx->dX + 2 * (size_t)Np, ctx->dAlpha, ctx->dBinv, ld, N, ctx->kp, gc, ctx->dGpart);
   hipLaunchKernelGGL(gpak_grad_reduce_f64, dim3(NSUM), dim3(256), 0, st, ctx->dGpart, (int)nblocks, ctx->dRed + 8);
   hipLaunchKernelGGL(gpak_lpdhyp_f64, dim3(1), dim3(1024), 0, st, N, ctx->dy, ctx->dF, ctx->sn2, ctx->dRed + 8 + NSUM);
   double red[NSUM + 1];
@@ -298,11 +352,28 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g) {
   float ms = 0;
   GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[3]));
   ctx->times.grad_ms = ms;
-  for (int p = 0; p < 6; p++) g[p] = red[p];                 // Kernel.cpp:1195-1233
-  g[6] = 2.0 * red[6] * ctx->expans[6];                      // :1241-1242
-  g[7] = 0.0;                                                // :1256-1257 (3-D)
-  g[8] = red[8];                                             // Kern_Bias::getGradients
-  const double sum_dW = 0.5 * red[7];                        // dW = 0.5 * sum(Q % K, 1)
-  g[9] = -1.0 * sum_dW * (2.0 / ctx->sn2) - red[9];          // GP_Utils.cpp:1226
+  int go = 0;
+  for (int t = 0; t < ctx->kp.nterms; t++) {
+    const KernTerm &T = ctx->kp.term[t];
+    const double A = red[9 + 2 * t], B = red[10 + 2 * t];
+    if (ctx->kinds[t] == GPAK_KERN_EXPANS) {
+      for (int p = 0; p < 6; p++) g[go + p] = red[p];            // Kernel.cpp:1195-1233
+      g[go + 6] = 2.0 * red[6] * ctx->expans[6];                 // :1241-1242
+      g[go + 7] = 0.0;                                           // :1256-1257 (3-D)
+      go += 8;
+    } else if (ctx->kinds[t] == GPAK_KERN_EXP) {                 // Kernel.cpp:671-690
+      g[go] = T.var2 * A;
+      g[go + 1] = B * sqrt(T.var2);
+      go += 2;
+    } else {                                                     // Kernel.cpp:512-538
+      g[go] = T.var2 * (T.iw / 2) * A;                           // g1/2 = -(sum R . D2), R = var2 QW KD2 (-iw/2)
+      g[go + 1] = -0.25 * T.var2 * A;                            // g2/2
+      g[go + 2] = T.var2 * B;                                    // g3/2 = sigma^2 sum QW . KD2
+      go += 3;
+    }
+  }
+  g[go++] = red[8];                                              // Kern_Bias::getGradients: trace(QW)
+  const double sum_dW = 0.5 * red[7];                            // dW = 0.5 * sum(Q % K, 1)
+  g[go] = -1.0 * sum_dW * (2.0 / ctx->sn2) - red[NSUM];          // GP_Utils.cpp:1226
   return GPAK_OK;
 }

@@ -144,6 +144,12 @@ class Gpak:
         self._check(self._lib.gpak_grad(self._h, _p(g)))
         return g
 
+    def GradLL_hyb(self, ng):
+        """Gradient of a general composition: children's blocks in order, bias, sn2."""
+        g = np.zeros(int(ng))
+        self._check(self._lib.gpak_grad_hyb(self._h, _p(g), int(ng)))
+        return g
+
     # -- measurement ---------------------------------------------------------------------
     def timing(self):
         t = _lib.PhaseTimes()

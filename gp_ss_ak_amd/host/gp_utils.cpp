@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
+#include <vector>
 
 #include "../../include/gpak.h"
 
@@ -92,13 +93,33 @@ double GP_utils::logLikelihood() const {
 double GP_utils::GradLL(mat &g) const {  // GP_Utils.cpp:1171-1262
   double nlz = logLikelihood();
   if (Chol_fail) return std::numeric_limits<double>::quiet_NaN();
-  double gd[10];
-  if (gpak_grad(ctx, gd) != GPAK_OK) gpak_host_fatal("gpak_grad", ctx);
-  // layout of g: kernel parameters in flat order, then the likelihood hyper-parameter
-  unsigned nk = KerenlW->getNPars();
-  for (unsigned i = 0; i < nk && i < 9; i++) g(i) = gd[i];
-  if (nk == 8) g(8) = gd[9];  // ExpAns without Bias
-  else g(nk) = gd[9];
+  // one device call evaluates GradLL + every child's getGradients; the result comes back as the
+  // stationary children's blocks in order, then the Bias entry, then the likelihood entry
+  std::vector<const Kernels *> leaves;
+  if (const HybKerns *h = dynamic_cast<const HybKerns *>(KerenlW)) {
+    for (unsigned i = 0; i < h->getNumKerns(); i++) leaves.push_back(h->getKern(i));
+  } else {
+    leaves.push_back(KerenlW);
+  }
+  int ng = 2;
+  for (const Kernels *c : leaves) {
+    if (dynamic_cast<const Kern_Bias *>(c)) continue;
+    if (dynamic_cast<const Kern_White *>(c)) {
+      // upstream, Kern_White inherits a getGradients that calls itself (Kernel.h:56-60, 257-283)
+      std::cerr << "GradLL: a White child has no gradient (the reference recurses without end here)." << std::endl;
+      exit(1);
+    }
+    ng += (int)c->getNPars();
+  }
+  std::vector<double> gd(ng);
+  if (gpak_grad_hyb(ctx, gd.data(), ng) != GPAK_OK) gpak_host_fatal("gpak_grad_hyb", ctx);
+  unsigned out = 0;
+  int in = 0;
+  for (const Kernels *c : leaves) {
+    if (dynamic_cast<const Kern_Bias *>(c)) { g(out++) = gd[ng - 2]; continue; }
+    for (unsigned i = 0; i < c->getNPars(); i++) g(out++) = gd[in++];
+  }
+  g(out) = gd[ng - 1];
   return nlz;
 }
 

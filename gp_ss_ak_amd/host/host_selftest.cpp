@@ -161,6 +161,13 @@ int main(int argc, char **argv) {
     GP_utils gp2(&H2, X, y, GP_utils::inf_laplace, GP_utils::likeL_Gaussian, GP_utils::mean_zero, 8, 1, 0, 0);
     printf("\"hyb5_npars\": %u,\n\"hyb5_K_sum\": %.17g,\n\"hyb5_K00\": %.17g,\n\"hyb5_nlz\": %.17g,\n", gp2.getNumPars(), s2,
            K2(0, 0), gp2.logLikelihood());
+    // gradient of a composition in CHILD order: Bias first, then RBF, then ExpAns
+    HybKerns H3(X);
+    H3.addNewKernel(&kb); H3.addNewKernel(&rbf); H3.addNewKernel(&ea);
+    GP_utils gp3(&H3, X, y, GP_utils::inf_laplace, GP_utils::likeL_Gaussian, GP_utils::mean_zero, 8, 1, 0, 0);
+    mat g3(1, gp3.getNumPars());
+    gp3.GradLL(g3);
+    print_vec("hyb3_grad", g3);
   }
   // model file round trip
   p(9) = 0.016;

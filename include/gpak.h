@@ -136,6 +136,13 @@ int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, 
  * written; g[10] = {8 ExpAns, bias, sn2}. */
 int gpak_grad(gpak_ctx *ctx, double *g);
 
+/* The same for any composition set with gpak_set_kernel: g holds the children's blocks in order
+ * (ExpAns 8, Exp 2, RBF 3 entries; Kernel.cpp:886-1263, 644-693, 491-540 as written -- the Exp/RBF
+ * children use GP_utils' D2 = the SUM of the children's D2), then the Bias entry (trace(QW)), then
+ * sn2; ng must be exactly that length.  Compositions with a White child: GPAK_ENOTIMPL (the
+ * reference has no gradient for it either). */
+int gpak_grad_hyb(gpak_ctx *ctx, double *g, int ng);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 typedef struct {
   double gram_ms;      /* fused fill of B = I + K/sn2 (lower tiles)                      */

@@ -848,3 +848,121 @@ void orc_grad_ref(const double *X, int N, const double *y, const double *K, cons
   g[9] = -1.0 * sdW - slp;
   free(yhat); free(R); free(DD2); free(QW); free(dW); free(Q);
 }
+
+
+/* GradLL for an arbitrary HybKerns composition (GP_Utils.cpp:1171-1284): the children's
+ * getGradients as written -- Kern_ExpAnisotropic (Kernel.cpp:886-1263, recomputes its own
+ * MahaDist), Kern_RBF (:491-540) and Kern_Exponential (:644-693), which both work on the D2
+ * ARGUMENT, i.e. GP_utils' member D2 = the SUM of the children's D2 (Kernel.cpp:151) --
+ * Kern_Bias (:370-377), then the likelihood hyper-parameter (:1222-1235).
+ * g: per child in order (8 / 2 / 3 entries), then bias (if has_bias), then sn2. */
+void orc_grad_hyb(const double *X, int N, const double *y, const double *K, const double *L, const double *alpha,
+                  int nterms, const int *kinds, const double *pars, int has_bias, double sn2, int mode, double *g) {
+  size_t NN = (size_t)N * N;
+  double Sw = sqrt(1.0 / sn2);
+  double *Q = (double *)calloc(NN, sizeof(double));
+  for (int i = 0; i < N; i++) Q[i + (size_t)i * N] = Sw;
+  orc_solve_chol(N, L, N, Q, N, N);
+  for (size_t t = 0; t < NN; t++) Q[t] *= (1.0 / Sw);
+  double *QW = (double *)malloc(sizeof(double) * NN);
+  double sdW = 0.0;
+  for (int j = 0; j < N; j++)
+    for (int i = 0; i < N; i++) {
+      size_t t = i + (size_t)j * N;
+      sdW += 0.5 * Q[t] * K[t];
+      QW[t] = Q[t] * (1.0 / sn2) - alpha[i] * alpha[j];
+    }
+  /* member D2 of GP_utils: sum of the children's D2 */
+  double *D2s = (double *)calloc(NN, sizeof(double)), *D = (double *)malloc(sizeof(double) * NN);
+  const double *p = pars;
+  for (int t = 0; t < nterms; t++) {
+    if (kinds[t] == 0) { double par[7]; pack_paramker(p, par); orc_mahadist(X, N, X, N, 3, par, mode, D); p += 8; }
+    else if (kinds[t] == 1) { orc_eucldist(X, N, X, N, 3, p[0], mode, D); p += 2; }
+    else { orc_eucldist(X, N, X, N, 3, p[0], mode, D); p += 3; }
+    for (size_t e = 0; e < NN; e++) D2s[e] += D[e];
+  }
+  int go = 0;
+  p = pars;
+  for (int t = 0; t < nterms; t++) {
+    if (kinds[t] == 0) {
+      /* reuse the ExpAns restatement on QW directly */
+      double par[7];
+      pack_paramker(p, par);
+      orc_mahadist(X, N, X, N, 3, par, mode, D);
+      double var2 = p[6] * p[6], S[9], Sp[6][9];
+      expans_S_matrices(p, S, Sp);
+      double *R = (double *)malloc(sizeof(double) * NN);
+      double gsig = 0.0;
+      for (int j = 0; j < N; j++)
+        for (int i = 0; i < N; i++) {
+          size_t e = i + (size_t)j * N;
+          double sd = sqrt(D[e]), kd2 = exp(-1.0 * sd);
+          double dk = sd == 0 ? 0.0 : kd2 * (-0.5 / sd);
+          if (i == j) dk = 0.0;
+          R[e] = var2 * QW[e] * dk;
+          gsig += kd2 * QW[e];
+        }
+      for (int q = 0; q < 6; q++) {
+        double M[9];
+        for (int e = 0; e < 9; e++) M[e] = S[e] * Sp[q][e];
+        double acc = 0.0;
+        for (int j = 0; j < N; j++)
+          for (int i = 0; i < N; i++) {
+            double ai = 0.0, aj = 0.0, dot = 0.0;
+            for (int c = 0; c < 3; c++) {
+              double u = 0.0;
+              for (int k = 0; k < 3; k++) {
+                double xi = X[i + (size_t)k * N], xj = X[j + (size_t)k * N];
+                ai += 2.0 * xi * xi * M[k + 3 * c];
+                aj += 2.0 * xj * xj * M[k + 3 * c];
+                u += xi * M[k + 3 * c];
+              }
+              dot += u * X[j + (size_t)c * N];
+            }
+            acc += R[i + (size_t)j * N] * (ai + aj - 4.0 * dot);
+          }
+        g[go + q] = acc;
+      }
+      g[go + 6] = 2.0 * gsig * p[6];
+      g[go + 7] = 0.0;
+      free(R);
+      go += 8; p += 8;
+    } else if (kinds[t] == 1) {   /* Kern_Exponential::getGradients, Kernel.cpp:644-693 */
+      double var2 = p[1] * p[1], g0 = 0.0, g1 = 0.0;
+      for (int j = 0; j < N; j++)
+        for (int i = 0; i < N; i++) {
+          size_t e = i + (size_t)j * N;
+          double sd = sqrt(D2s[e]), kd2 = exp(-1.0 * sd);
+          double dk = (i == j || sd == 0) ? 0.0 : kd2 * (-0.5 / sd);   /* :665-669 (diag filled with 0) */
+          g0 += var2 * QW[e] * dk * D2s[e];                            /* :671-680 */
+          g1 += (QW[e] * kd2) * kd2;                                   /* :682-690: (Q % KD2) . KD2 */
+        }
+      g[go] = g0; g[go + 1] = g1 * p[1];
+      go += 2; p += 2;
+    } else {                      /* Kern_RBF::getGradients, Kernel.cpp:491-540 */
+      double var2 = p[2] * p[2], iw = p[1], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (size_t e = 0; e < NN; e++) {
+        double kd2 = exp(-0.5 * iw * D2s[e]);
+        double dk = exp(-iw / 2 * D2s[e]) * (-iw / 2);
+        s1 += var2 * QW[e] * dk * D2s[e];            /* R . D2 */
+        s2 += -0.5 * (var2 * QW[e] * kd2) * D2s[e];  /* Qwidth */
+        s3 += QW[e] * kd2;
+      }
+      g[go] = (-2.0 * s1) / 2;                       /* :518, :536 */
+      g[go + 1] = s2 / 2;                            /* :521, :537 */
+      g[go + 2] = ((s3 * p[2] + s3 * p[2]) * p[2]) / 2;   /* :523-531, :538 */
+      go += 3; p += 3;
+    }
+  }
+  if (has_bias) {
+    double tr = 0.0;
+    for (int i = 0; i < N; i++) tr += QW[i + (size_t)i * N];
+    g[go++] = tr;
+  }
+  double *yhat = (double *)malloc(sizeof(double) * N);
+  gemv_full(N, K, alpha, yhat);
+  double slp = 0.0;
+  for (int i = 0; i < N; i++) { double r = y[i] - yhat[i]; slp += (1.0 / sn2) * r * r - 1.0; }
+  g[go] = -1.0 * sdW * (2.0 / sn2) - slp;
+  free(yhat); free(D); free(D2s); free(QW); free(Q);
+}

@@ -114,6 +114,10 @@ void orc_grad_ref(const double *X, int N, const double *y, const double *K,
                   const double *L, const double *alpha, const double *expans,
                   double bias, double sn2, int mode, double *g);
 
+/* GradLL for an arbitrary composition; see the .c file.  g: children in order (8 / 2 / 3), bias, sn2 */
+void orc_grad_hyb(const double *X, int N, const double *y, const double *K, const double *L, const double *alpha,
+                  int nterms, const int *kinds, const double *pars, int has_bias, double sn2, int mode, double *g);
+
 #ifdef __cplusplus
 }
 #endif

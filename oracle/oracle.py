@@ -186,3 +186,17 @@ def grad_ref(X, y, K, L, alpha, expans, bias, sn2, mode=DIST_EXPANSION):
     lib().orc_grad_ref(_p(X), C.c_int(N), _p(y), _p(K), _p(L), _p(alpha), _p(e), C.c_double(bias),
                        C.c_double(sn2), C.c_int(mode), _p(g))
     return g
+
+
+def grad_hyb(X, y, K, L, alpha, terms, has_bias, sn2, mode=DIST_EXPANSION):
+    X, K, L = _f(X), _f(K), _f(L)
+    N = X.shape[0]
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    kinds = (C.c_int * len(terms))(*[int(k) for k, _ in terms])
+    pars = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64) for _, p in terms]))
+    ng = sum({0: 8, 1: 2, 2: 3}[int(k)] for k, _ in terms) + (1 if has_bias else 0) + 1
+    g = np.zeros(ng)
+    lib().orc_grad_hyb(_p(X), C.c_int(N), _p(y), _p(K), _p(L), _p(alpha), C.c_int(len(terms)), kinds, _p(pars),
+                       C.c_int(1 if has_bias else 0), C.c_double(sn2), C.c_int(mode), _p(g))
+    return g

@@ -168,7 +168,26 @@ def test_other_kernel_compositions(gp, orc, mode):
     assert rel(mean, mo) <= tp and rel(var, vo) <= tp
     with pytest.raises(gpak.GpakError) as ei:
         gp.GradLL()
-    assert ei.value.status == gpak.ENOTIMPL
+    assert ei.value.status == gpak.ENOTIMPL              # fixed-length gradient: ExpAns(+Bias) only
+    with pytest.raises(gpak.GpakError) as ei:
+        gp.GradLL_hyb(8 + 2 + 3 + 2)
+    assert ei.value.status == gpak.ENOTIMPL              # White child: no gradient upstream either
+    # without the White child: the children's getGradients as written (Exp / RBF on the summed D2)
+    gp.set_kernel(terms, BIAS, 0.0, SN2, mode)
+    g = gp.GradLL_hyb(8 + 2 + 3 + 2)
+    K0 = orc.gram_hyb(X, X, terms, BIAS, 0.0, mode)
+    info0, a0, L0 = orc.nlz_lean(K0, y, SN2)
+    go = orc.grad_hyb(X, y, K0, L0, a0, terms, True, SN2, mode)
+    assert np.abs(g - go).max() <= (1e-8 if mode == gpak.DIST_DIRECT else 1e-5) * np.abs(go).max()
+    # a composition without ExpAns
+    t2 = [(gpak.KERN_RBF, [0.7, 1.1, 0.6]), (gpak.KERN_EXP, [0.4, 0.8])]
+    gp.set_kernel(t2, BIAS, 0.0, SN2, mode)
+    g = gp.GradLL_hyb(3 + 2 + 2)
+    K2 = orc.gram_hyb(X, X, t2, BIAS, 0.0, mode)
+    info2, a2, L2 = orc.nlz_lean(K2, y, SN2)
+    go = orc.grad_hyb(X, y, K2, L2, a2, t2, True, SN2, mode)
+    assert abs(gp.logLikelihood() - info2.nlz) <= tol * abs(info2.nlz)
+    assert np.abs(g - go).max() <= (1e-8 if mode == gpak.DIST_DIRECT else 1e-5) * np.abs(go).max()
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)   # back to the default composition for later tests
 
 

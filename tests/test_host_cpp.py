@@ -131,6 +131,13 @@ def test_class_surface_matches_oracle(orc, tmp_path):
     assert r["hyb5_npars"] == 8 + 3 + 2 + 1 + 1 + 1
     assert abs(r["hyb5_K_sum"] - K5.sum()) <= 1e-12 * abs(K5.sum()) and abs(r["hyb5_K00"] - K5[0, 0]) <= 1e-14
     assert abs(r["hyb5_nlz"] - info5.nlz) <= 1e-9 * abs(info5.nlz)
+    # gradient in child order {Bias, RBF, ExpAns} + likelihood
+    t3 = [(2, [0.5, 0.9, 0.5]), (0, E)]
+    K3 = orc.gram_hyb(X, X, t3, 0.2, 0.0, orc.DIST_DIRECT)
+    info3, a3, L3 = orc.nlz_lean(K3, y, 0.016)
+    go = orc.grad_hyb(X, y, K3, L3, a3, t3, True, 0.016, orc.DIST_DIRECT)   # RBF(3), ExpAns(8), bias, sn2
+    want = np.concatenate([[go[11]], go[0:3], go[3:11], [go[12]]])
+    assert np.abs(np.array(r["hyb3_grad"]) - want).max() <= 1e-8 * np.abs(want).max()
     assert np.allclose(r["params_reloaded"], [float(f"{v:.6g}") for v in list(E) + [0.2, 0.016]], rtol=0, atol=0)
 
 
