@@ -252,7 +252,7 @@ int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *p
     if (kinds[t] == GPAK_KERN_EXPANS) {
       gpak_build_siginv(p, T.A);
       T.var2 = p[6] * p[6]; T.profile = GPAK_PROFILE_EXPSQRT;
-      if (t == 0) memcpy(ctx->expans, p, sizeof(double) * 8);
+      memcpy(ctx->expans, p, sizeof(double) * 8);  // the (single) ExpAns child, wherever it sits
       p += 8;
     } else if (kinds[t] == GPAK_KERN_EXP) {   // {Hayper_Euc_Exp, Sigma_Exp}, Kernel.cpp:576-600
       const double s = 1.0 / p[0];             // mlA: X * hyp^-2 on one side == both sides scaled by 1/hyp
