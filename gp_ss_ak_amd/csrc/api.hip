@@ -124,6 +124,7 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
   hipMalloc(&ctx->dQueue, sizeof(int) * 8 * 256);
   if (const char *pe = getenv("GPAK_PERSISTENT")) ctx->persistent = atoi(pe) != 0;
+  if (const char *pe = getenv("GPAK_PERSIST_TILES")) ctx->persist_tiles = atoi(pe) > 0 ? atoi(pe) : 8;
   if (const char *pe = getenv("GPAK_FWD_IN_FACTOR")) ctx->fwd_in_factor = atoi(pe) != 0;
   const char *nb = getenv("GPAK_NB_OUTER");
   if (nb) ctx->nb_outer = atoi(nb);

@@ -192,7 +192,7 @@ void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double
 // all queues are exhausted (a bounded number of atomic adds), so the grid always drains.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void gpak_syrk_trailing_f64(int K, const double *A, long lda, double *C,
-                                                                  long ldc, int mt, int *queue) {
+                                                                  long ldc, int mt, int *queue, int max_tiles) {
   __shared__ double lds[2][2][KB][LDS_LD];
   int *sh_next = reinterpret_cast<int *>(&lds[0][0][0][128]);  // row padding: never written by the LDS-DMA
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gpak_syrk_trailing_f64(int K, const do
   int cur = *sh_next;
   if (cur < 0) return;
   const int nstage = K / KB;
-  int bufoff = 0;
+  int bufoff = 0, done = 0;
   {
     const double *Ag = A + (size_t)(cur >> 16) * TM + 2 * lane;
     const double *Bg = A + (size_t)(cur & 0xffff) * TN + 2 * lane;
@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256, 2) void gpak_syrk_trailing_f64(int K, const do
     __syncthreads();  // vmcnt(0) + barrier: this tile's first stage has landed
     for (int st = 0; st + 1 < nstage; st++) {
       const int buf = (st + bufoff) & 1;
-      if (st + 2 == nstage && t == 0) *sh_next = fetch();  // published by this stage's barrier
+      // a workgroup retires after max_tiles tiles so that CU slots keep turning over for the
+      // look-ahead panel's kernels (a grid that never exits starves them)
+      if (st + 2 == nstage && t == 0) *sh_next = (done + 1 < max_tiles) ? fetch() : -1;  // published by this stage's barrier
       GPAK_PSTAGE(buf ^ 1, (size_t)(st + 1) * KB, Ag, Bg)
       GPAK_PCOMPUTE(buf)
       __builtin_amdgcn_sched_barrier(0);
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void gpak_syrk_trailing_f64(int K, const do
     if (nxt < 0) break;
     cur = nxt;
     bufoff = lbuf ^ 1;
+    done++;
   }
 #undef GPAK_PSTAGE
 #undef GPAK_PCOMPUTE
@@ -304,9 +307,13 @@ __global__ __launch_bounds__(256, 2) void gpak_syrk_trailing_f64(int K, const do
 
 // C (mt x mt lower tiles) -= A A^T with K columns; queue = 8 device ints owned by the caller
 void gpak_launch_syrk_trailing(hipStream_t st, int mt, int K, const double *A, long lda, double *C, long ldc,
-                               int *queue) {
+                               int *queue, int max_tiles) {
   hipMemsetAsync(queue, 0, 8 * sizeof(int), st);
-  hipLaunchKernelGGL(gpak_syrk_trailing_f64, dim3(512), dim3(256), 0, st, K, A, lda, C, ldc, mt, queue);
+  const long tiles = (long)mt * (mt + 1) / 2;
+  long wgs = (tiles + max_tiles - 1) / max_tiles + 64;   // spare workgroups exit at once when the queues are empty
+  wgs = (wgs + 7) / 8 * 8;
+  hipLaunchKernelGGL(gpak_syrk_trailing_f64, dim3((unsigned)wgs), dim3(256), 0, st, K, A, lda, C, ldc, mt, queue,
+                     max_tiles);
 }
 
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,

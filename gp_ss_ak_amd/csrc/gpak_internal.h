@@ -75,7 +75,8 @@ struct gpak_ctx {
   int *dInfo = nullptr;      // first failing column (1-based) or 0
   int *dQueue = nullptr;     // ring of 8-int tile queues for the persistent trailing update
   int queue_next = 0;
-  bool persistent = false;   // the persistent trailing kernel starves the look-ahead panel of CU slots
+  bool persistent = false;   // multi-tile trailing-update workgroups (gpak_syrk_trailing_f64)
+  int persist_tiles = 8;     // tiles a workgroup processes before it retires
   enum { M_NONE, M_B, M_L } mstate = M_NONE;
   bool alpha_ok = false, nlz_ok = false;
   int failed_col = 0;
@@ -154,7 +155,7 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
 void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double *Pv, long ldp, double *Clocal,
                              long ldc, int rt0, int P, int rank, int tpb, int lt0);
 void gpak_launch_syrk_trailing(hipStream_t st, int mt, int K, const double *A, long lda, double *C, long ldc,
-                               int *queue);
+                               int *queue, int max_tiles);
 
 // ---- gemm_f32.hip (fp32 prediction path) ---------------------------------------------------
 void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha, const float *A, long lda,
