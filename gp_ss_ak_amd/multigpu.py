@@ -148,7 +148,7 @@ class HipEngine:
 class DistGP:
     """The hot path on P ranks.  Every rank calls the same methods in the same order."""
 
-    def __init__(self, engine, X, y, nb=512, group=None):
+    def __init__(self, engine, X, y, nb=512, group=None, pipeline=None):
         torch = _torch()
         import torch.distributed as dist
         self.dist = dist
@@ -186,6 +186,10 @@ class DistGP:
         self.alpha = engine.zeros(self.Np)
         self.params = None
         self.bytes_broadcast = 0
+        # sub-panel broadcasts pay off when there IS a transfer to hide; one rank keeps whole panels
+        # (235.6 vs 231.0 ms at N=32768 on one GPU)
+        self.pipeline = ((os.environ.get("GPAK_DIST_PIPELINE", "1") != "0" and self.P > 1) if pipeline is None
+                         else bool(pipeline))
 
     def start(self, b):
         return b * self.nb
@@ -234,6 +238,18 @@ class DistGP:
 
     def factor(self):
         """Returns 0, or the first failing column (1-based) like LAPACK dpotrf's info."""
+        return self._factor_pipelined() if self.pipeline else self._factor_whole_panels()
+
+    def _finish_info(self):
+        torch = _torch()
+        info = self.info[:1].to(torch.int64)
+        if self.P > 1:
+            self.dist.all_reduce(info, op=self.dist.ReduceOp.MIN, group=self.group)
+        v = int(info.item())
+        return 0 if v == INT_MAX else v
+
+    def _factor_whole_panels(self):
+        """One broadcast per outer panel (the simple schedule; kept for comparison and tests)."""
         torch = _torch()
         self.info.fill_(INT_MAX)
         self.bytes_broadcast = 0
@@ -282,11 +298,102 @@ class DistGP:
                     panel_next.record_stream(main)
                 panel.record_stream(ps)
             panel = panel_next
-        info = self.info[:1].to(torch.int64)
-        if self.P > 1:
-            self.dist.all_reduce(info, op=self.dist.ReduceOp.MIN, group=self.group)
-        v = int(info.item())
-        return 0 if v == INT_MAX else v
+        return self._finish_info()
+
+    # The serial chain of the distributed factorisation is  factor(b) -> transfer -> update of column b+1
+    # -> factor(b+1) ...; per outer panel that is 4 x ~150 us of factor work plus the transfer of up to
+    # (N x nb) doubles.  Sending the panel in 128-column sub-panels as they are finished hides three
+    # quarters of the transfer under the owner's remaining factor work, and the next owner applies each
+    # sub-panel to its column as it lands, so only the last quarter is exposed.
+    def _produce(self, b):
+        """Factor block column b on its owner, 128 columns at a time; broadcast each sub-panel's rows below
+        the diagonal block as soon as they exist; the owner of b+1 applies them to its column as they
+        arrive.  Runs on the side stream.  Returns (packed panel or None, broadcast handles)."""
+        eng, ld, Np = self.eng, self.ld, self.Np
+        J, W = self.start(b), self.width(b)
+        rows = Np - (J + W)
+        own = self.rank == self.owner(b)
+        nxt = b + 1
+        buf = eng.empty(W * rows) if rows > 0 else None
+        handles = []
+        for s in range(W // TILE):
+            if own:
+                sub = self.blk[b][s * TILE * ld:(s + 1) * TILE * ld]
+                eng.factor_panel(sub, ld, Np, J + s * TILE, TILE,
+                                 self.inv[b][s * 2 * TILE * TILE:(s + 1) * 2 * TILE * TILE], self.info)
+                rem = W - (s + 1) * TILE
+                if rem > 0:  # the rest of the owner's own block column
+                    eng.update_block(sub, ld, 0, TILE, self.blk[b][(s + 1) * TILE * ld:], ld, Np,
+                                     J + (s + 1) * TILE, rem)
+                if rows > 0:
+                    buf[s * TILE * rows:(s + 1) * TILE * rows].view(TILE, rows).copy_(
+                        sub.view(TILE, ld)[:, J + W:Np])
+            if rows > 0:
+                chunk = buf[s * TILE * rows:(s + 1) * TILE * rows]
+                h = self._bcast(chunk, self.owner(b), async_op=True)
+                self.bytes_broadcast += chunk.numel() * 8
+                if h is not None:
+                    handles.append(h)
+                if nxt < self.nJ and self.rank == self.owner(nxt):
+                    if h is not None:
+                        h.wait()
+                    eng.update_block(chunk, rows, J + W, TILE, self.blk[nxt], ld, Np, self.start(nxt),
+                                     self.width(nxt))
+        return buf, handles
+
+    def _factor_pipelined(self):
+        """Column c receives panel b <= c-3 in the bulk update of step b (main stream), panel c-2 as one
+        K=nb update and panel c-1 sub-panel by sub-panel (both on the side stream, in that order)."""
+        torch = _torch()
+        self.info.fill_(INT_MAX)
+        self.bytes_broadcast = 0
+        streams = getattr(self.eng, "has_streams", False)
+        main = torch.cuda.current_stream() if streams else None
+        ps = self.eng.panel_stream() if streams else None
+
+        class _side:  # `with side:` = queue on the panel stream when the engine has streams
+            def __enter__(s2):
+                if streams:
+                    s2.c = torch.cuda.stream(ps)
+                    s2.c.__enter__()
+
+            def __exit__(s2, *a):
+                if streams:
+                    s2.c.__exit__(*a)
+        side = _side()
+        if streams:
+            ps.wait_stream(main)  # the fill
+        with side:
+            panel, handles = self._produce(0)
+        for b in range(self.nJ):
+            J, W = self.start(b), self.width(b)
+            rows = self.Np - (J + W)
+            if rows <= 0:
+                break
+            nxt, nn = b + 1, b + 2
+            # panel b is complete on this rank once its broadcasts (non-owners) / packs (owner) are done
+            for h in handles:
+                h.wait()
+            if streams:
+                main.wait_stream(ps)
+                panel.record_stream(main)
+            panel_next, handles_next = None, []
+            if nxt < self.nJ:
+                if streams:
+                    ps.wait_stream(main)  # bulk update b-1 has finished with block column b+2
+                with side:
+                    if nn < self.nJ and self.rank == self.owner(nn):
+                        self.eng.update_block(panel, rows, J + W, W, self.blk[nn], self.ld, self.Np,
+                                              self.start(nn), self.width(nn))
+                    panel_next, handles_next = self._produce(nxt)
+            lb0 = next((i for i, c in enumerate(self.owned) if c > nn), None)
+            if lb0 is not None:
+                self.eng.update_cyclic(panel, rows, J + W, W, self.local, self.ld, self.Np, self.nb, self.P,
+                                       self.rank, lb0, len(self.owned), self.width(self.owned[-1]))
+            panel, handles = panel_next, handles_next
+        if streams:
+            main.wait_stream(ps)
+        return self._finish_info()
 
     # ---- solve_chol (GP_Utils.cpp:841-845) with the factor distributed by block columns -------
     def solve(self, rhs):

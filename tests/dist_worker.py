@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--engine", choices=["numpy", "hip"], default="numpy")
     ap.add_argument("--mode", type=int, default=1)
     ap.add_argument("--sn2", type=float, default=None)
+    ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,7 +36,7 @@ def main():
         from np_engine import NumpyEngine
         eng = NumpyEngine()
     X, y = synth.drillholes(a.n)
-    gp = multigpu.DistGP(eng, X, y, nb=a.nb)
+    gp = multigpu.DistGP(eng, X, y, nb=a.nb, pipeline=bool(a.pipeline))
     sn2 = synth.DEFAULT_SN2 if a.sn2 is None else a.sn2
     gp.set_params(synth.DEFAULT_EXPANS, synth.DEFAULT_BIAS, sn2, a.mode)
     nlz = gp.nlz()

@@ -29,14 +29,14 @@ def free_port():
     return p
 
 
-def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, timeout=600):
+def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, timeout=600, pipeline=1):
     port = free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
         for r in range(world):
             cmd = [sys.executable, os.path.join(HERE, "dist_worker.py"), "--rank", str(r), "--world", str(world),
                    "--port", str(port), "--n", str(n), "--nb", str(nb), "--engine", engine, "--mode", str(mode),
-                   "--out", os.path.join(d, f"r{r}.json")]
+                   "--pipeline", str(pipeline), "--out", os.path.join(d, f"r{r}.json")]
             if sn2 is not None:
                 cmd += ["--sn2", str(sn2)]
             env = dict(os.environ, OMP_NUM_THREADS="2")
@@ -54,9 +54,12 @@ def oracle_ref(orc, n, mode=1):
     return info, alpha
 
 
-@pytest.mark.parametrize("world,n,nb", [(2, 300, 128), (3, 700, 128), (2, 600, 256)])
-def test_gloo_cpu_schedule_matches_oracle(orc, world, n, nb):
-    res = run_world(world, n, nb)
+@pytest.mark.parametrize("world,n,nb,pipeline", [(2, 300, 128, 1), (3, 700, 128, 1), (2, 600, 256, 1),
+                                                  (3, 1500, 256, 1), (4, 1400, 256, 1), (2, 600, 256, 0),
+                                                  (3, 700, 128, 0)])
+def test_gloo_cpu_schedule_matches_oracle(orc, world, n, nb, pipeline):
+    """pipeline=1: sub-panel broadcasts (the default schedule); 0: one broadcast per outer panel."""
+    res = run_world(world, n, nb, pipeline=pipeline)
     info, alpha = oracle_ref(orc, n)
     owned = sorted(b for r in res for b in r["owned"])
     assert owned == list(range(res[0]["nJ"]))                       # every block column has one owner
@@ -80,9 +83,10 @@ def test_single_process_schedule_matches_oracle(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,nb", [(1, 1000, 256), (2, 1500, 256), (2, 1100, 512)])
-def test_hip_engine_schedule_matches_oracle(orc, world, n, nb):
-    res = run_world(world, n, nb, engine="hip")
+@pytest.mark.parametrize("world,n,nb,pipeline", [(1, 1000, 256, 1), (2, 1500, 256, 1), (2, 1100, 512, 1),
+                                                  (3, 2500, 256, 1), (2, 1500, 256, 0)])
+def test_hip_engine_schedule_matches_oracle(orc, world, n, nb, pipeline):
+    res = run_world(world, n, nb, engine="hip", pipeline=pipeline)
     info, alpha = oracle_ref(orc, n)
     for r in res:
         assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
