@@ -148,7 +148,7 @@ def run_single(args):
         "phases_ms_per_step": {k: phases[k] / args.steps for k in ("gram_ms", "factor_ms", "solve_ms", "nlz_ms")},
         "nlz": nlz,
         "roofline": {
-            "kernel": "gpak_gemm_nt_f64<true> (Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
+            "kernel": "gpak_gemm_nt_f64_rs (Cholesky trailing update, v_mfma_f64_16x16x4_f64, register-streamed operands)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": PEAK_F64_MFMA_TFLOPS,

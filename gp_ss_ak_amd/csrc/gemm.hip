@@ -16,10 +16,12 @@
 // the f64 16x16x4 result layout is col=lane&15,row=(lane>>4)+4*reg, so with the swap a
 // lane group writes 16 consecutive matrix rows (128 B) of one column.
 #include <cstdlib>
+#include <cstring>
 
 #include "gpak_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define TM 128
 #define TN 128
@@ -72,12 +74,20 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
     if (art < gct) return;
   }
   __shared__ double lds[2][2][KB][LDS_LD];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  // the wave index as a SCALAR: everything the LDS-DMA needs (LDS row, k-row of the source) is then
+  // computed on the scalar unit.  Vector ALU instructions share the issue port with the MFMAs; ~35 of
+  // them per stage for address arithmetic cost 6 % of the MFMA rate
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w & 1, wc = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  const double *Ag = A + (size_t)art * TM + 2 * lane;  // per-lane source of a 16-B piece
-  const double *Bg = B + (size_t)gct * TN + 2 * lane;
+  // source of a 16-B piece = scalar base (tile, k-row) + 32-bit lane offset: the global_load_lds
+  // "saddr + voffset" form, so advancing k is scalar arithmetic
+  const char *Au = reinterpret_cast<const char *>(A + (size_t)art * TM);
+  const char *Bu = reinterpret_cast<const char *>(B + (size_t)gct * TN);
+  const unsigned voff = (unsigned)lane * 16u;
+  const size_t lda8 = (size_t)lda * 8, ldb8 = (size_t)ldb * 8;
 
   d4 acc[4][4];
 #pragma unroll
@@ -95,10 +105,10 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
 #define GPAK_STAGE(buf_, kbase_)                                                                  \
   _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                 \
     const size_t k_ = (size_t)(kbase_) + w + 4 * s;                                               \
-    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + k_ * lda), (lptr_t)&lds[buf_][0][w + 4 * s][0], \
-                                     16, 0, 0);                                                   \
-    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + k_ * ldb), (lptr_t)&lds[buf_][1][w + 4 * s][0], \
-                                     16, 0, 0);                                                   \
+    __builtin_amdgcn_global_load_lds((gptr_t)(Au + k_ * lda8 + voff),                             \
+                                     (lptr_t)&lds[buf_][0][w + 4 * s][0], 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gptr_t)(Bu + k_ * ldb8 + voff),                             \
+                                     (lptr_t)&lds[buf_][1][w + 4 * s][0], 16, 0, 0);              \
   }
 
   // k0_by_row: A (and B) are upper triangular in (row, k), so tile row ti only has k >= ti*128
@@ -118,14 +128,26 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
             acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0); \
   }
 
-  for (int st = st_begin; st + 1 < nstage; st++) {
-    const int buf = st & 1;
+  // Two stages per trip so that the buffer index is a compile-time constant (LDS offsets become
+  // immediates, no per-stage vector address arithmetic); st_begin is even (0 or a multiple of 8).
+  int st = st_begin;
+  for (; st + 2 < nstage; st += 2) {
     // stage st+1 streams into the other buffer while this stage's MFMAs run
-    GPAK_STAGE(buf ^ 1, (size_t)(st + 1) * KB)
-    GPAK_COMPUTE(buf)
+    GPAK_STAGE(1, (size_t)(st + 1) * KB)
+    GPAK_COMPUTE(0)
     // keep this stage's MFMAs ABOVE the wait+barrier: without the fence hipcc reads all
     // fragments up front and sinks 61 of the 64 MFMAs below the barrier, so every wave sits
     // out the full LDS-DMA latency before it computes
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    GPAK_STAGE(0, (size_t)(st + 2) * KB)
+    GPAK_COMPUTE(1)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  if (st + 2 == nstage) {  // an even number of stages: one more full stage before the last
+    GPAK_STAGE(1, (size_t)(st + 1) * KB)
+    GPAK_COMPUTE(0)
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
@@ -166,6 +188,147 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
 #undef GPAK_COMPUTE
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-streaming kernel (the default): no LDS, no barriers.  Every lane fetches the elements of
+// its own MFMA fragments straight from global memory with 16-B loads, RS_D k-steps ahead in a
+// register ring; the four waves of a workgroup (2x2 over the 128x128 tile) never wait for one
+// another, and operand sharing between the waves of a CU is left to the vector L1 / the XCD's L2
+// (the super-tile map keeps the 64 workgroups of an XCD on the same 8+8 operand panels).
+// Against the LDS-staged kernel above: 71.4 vs 66.3 TFLOP/s at N=32768, K=512 (74.1 vs 68.6 for
+// K -> inf; back-to-back MFMA issue alone reaches 77.7): what the LDS version loses is not memory
+// latency (an L2-resident operand set runs no faster) but the barrier per stage and the LDS-DMA /
+// ds_read issue slots next to the MFMAs.
+// ---------------------------------------------------------------------------------------
+template <int RS_D, int RS_OCC>
+__global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double alpha, const double *A, long lda,
+                                                               const double *B, long ldb, double beta, double *C,
+                                                               long ldc, int rb0, int cb0, int lower_skip, int mt,
+                                                               int nt, int k0_by_row, int cyc_P, int cyc_rank,
+                                                               int cyc_tpb, int cyc_lt0) {
+  int ti, tj;
+  {
+    const int b = blockIdx.x, q = b >> 3;
+    const int slot = q & 63;
+    const int ssel = (q >> 6) * 8 + (b & 7);
+    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
+    int si, sj = 0;
+    if (lower_skip) {
+      int rem = ssel;
+      while (sj < SC && rem >= SR - sj) { rem -= SR - sj; sj++; }
+      si = sj + rem;
+    } else {
+      sj = ssel / SR;
+      si = ssel - sj * SR;
+    }
+    if (sj >= SC) return;
+    ti = si * 8 + (slot & 7);
+    tj = sj * 8 + (slot >> 3);
+    if (ti >= mt || tj >= nt) return;
+    if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
+  }
+  int gct = tj, art = ti;
+  if (cyc_P) {
+    const int lt = cyc_lt0 + tj;
+    gct = ((lt / cyc_tpb) * cyc_P + cyc_rank) * cyc_tpb + (lt % cyc_tpb);
+    art = rb0 + ti;
+    if (art < gct) return;
+  }
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w & 1, wc = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int kstep0 = k0_by_row ? (rb0 + ti) * (TM / 4) : 0;
+  const int nk = K / 4;
+  // One 16-B load feeds TWO fragments: lane (l15, l4) fetches rows 32h + 2*l15, +1 of k-column 4s + l4 and
+  // uses them as its element of tiles 2h and 2h+1, i.e. MFMA tile i covers the rows 32(i>>1) + 2j + (i&1),
+  // j = 0..15, of the wave's 64 -- a fixed permutation that the epilogue undoes (16 lanes = 256 B contiguous).
+  const d2 *Ap = reinterpret_cast<const d2 *>(A + (size_t)art * TM + wr * 64 + 2 * l15 + (size_t)(4 * kstep0 + l4) * lda);
+  const d2 *Bp = reinterpret_cast<const d2 *>(B + (size_t)gct * TN + wc * 64 + 2 * l15 + (size_t)(4 * kstep0 + l4) * ldb);
+  const size_t sa = 2 * (size_t)lda, sb = 2 * (size_t)ldb;  // 4 k-columns, in 16-B units
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  d2 ra[RS_D][2], rbv[RS_D][2];
+#define RS_LOAD(slot_)                                                             \
+  _Pragma("unroll") for (int h = 0; h < 2; h++) ra[slot_][h] = Ap[16 * h];        \
+  _Pragma("unroll") for (int h = 0; h < 2; h++) rbv[slot_][h] = Bp[16 * h];       \
+  Ap += sa;                                                                        \
+  Bp += sb;
+#define RS_MFMA(slot_)                                                             \
+  _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                 \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                             \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(rbv[slot_][ni >> 1][ni & 1], ra[slot_][mi >> 1][mi & 1], \
+                                                             acc[mi][ni], 0, 0, 0);
+
+  // ring of RS_D k-steps in flight; n >= 32 k-steps always (K >= 128, k0_by_row leaves >= one tile)
+  const int n = nk - kstep0;
+#pragma unroll
+  for (int s = 0; s < RS_D; s++) { RS_LOAD(s) }
+  int g = 0;
+  for (; g + 2 * RS_D <= n; g += RS_D) {
+#pragma unroll
+    for (int s = 0; s < RS_D; s++) {
+      RS_MFMA(s)
+      RS_LOAD(s)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int r = n - (g + RS_D);  // k-steps not yet requested: 0 .. RS_D-1
+#pragma unroll
+  for (int s = 0; s < RS_D; s++) {
+    RS_MFMA(s)
+    if (s < r) { RS_LOAD(s) }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 0; s < RS_D; s++)
+    if (s < r) { RS_MFMA(s) }
+#undef RS_LOAD
+#undef RS_MFMA
+
+  // in-place product (the panel solve P <- P * inv^T, one tile column): the workgroup's C rows are its
+  // own A rows, which the neighbouring wave is still reading -- the only place the waves must meet
+  if (A == C) __syncthreads();
+  // lane holds, of tile (mi, ni): C row 32(mi>>1) + 2*l15 + (mi&1), C columns 32(ni>>1) + 2(l4 + 4r) + (ni&1)
+  double *Cg = C + (size_t)art * TM + wr * 64 + 2 * l15 + ((size_t)tj * TN + wc * 64) * ldc;
+#define RS_COL(ni_, r_) ((size_t)(32 * ((ni_) >> 1) + 2 * (l4 + 4 * (r_)) + ((ni_) & 1)) * ldc)
+  if (beta == 0.0) {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          d2 v = {alpha * acc[2 * h][ni][r], alpha * acc[2 * h + 1][ni][r]};
+          *reinterpret_cast<d2 *>(Cg + 32 * h + RS_COL(ni, r)) = v;
+        }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int nh = 0; nh < 2; nh++) {
+        d2 c[2][4];
+#pragma unroll
+        for (int n2 = 0; n2 < 2; n2++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) c[n2][r] = *reinterpret_cast<const d2 *>(Cg + 32 * h + RS_COL(2 * nh + n2, r));
+#pragma unroll
+        for (int n2 = 0; n2 < 2; n2++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            d2 v = {fma(alpha, acc[2 * h][2 * nh + n2][r], beta * c[n2][r].x),
+                    fma(alpha, acc[2 * h + 1][2 * nh + n2][r], beta * c[n2][r].y)};
+            *reinterpret_cast<d2 *>(Cg + 32 * h + RS_COL(2 * nh + n2, r)) = v;
+          }
+      }
+  }
+#undef RS_COL
+}
+
 // Trailing update of ALL block columns a rank owns beyond local tile column lt0, in one launch:
 // C_local[rows >= rt0*128, local tile columns lt0..] -= Pv[rows] * Pv[global column rows]^T where
 // Pv is the panel addressed by global row (virtual base).  See the cyc_* comment in the kernel.
@@ -175,8 +338,8 @@ void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double
   const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
   const long nsuper = (long)SR * SC;
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
-  hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, -1.0, Pv, ldp, Pv, ldp, 1.0, Clocal, ldc, rt0, 0,
-                     0, mt, nt, 0, P, rank, tpb, lt0);
+  hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2>), grid, block, 0, st, K, -1.0, Pv, ldp, Pv, ldp, 1.0, Clocal, ldc,
+                     rt0, 0, 0, mt, nt, 0, P, rank, tpb, lt0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -328,7 +491,12 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
     nsuper = (long)SR * SC;
   }
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
-  if (trailing)
+  // GPAK_GEMM=lds selects the LDS-staged kernel (kept for comparison); default: register streaming
+  static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
+  if (!use_lds)
+    hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
+  else if (trailing)
     hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
                        row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
   else

@@ -268,7 +268,8 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
 // Panel factorisation of one outer block column [J, J+W): all rows below it.
 // M is addressed with GLOBAL (row, column) indices; only columns [J, J+W) are touched, so a
 // rank that stores just this block column passes a virtual base (see dev_api.hip).
-void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info) {
+// One level: 128-column steps, each followed by the K=128 update of the columns [j+128, J+W).
+static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info) {
   for (int j = J; j < J + W; j += PB) {
     double *inv = inv_base + (size_t)(j / PB) * 2 * PB * PB;
     gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info);
@@ -280,6 +281,20 @@ void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W,
       if (nct > 0)
         gpak_launch_gemm_nt(st, mt, nct, PB, -1.0, P, ld, P, ld, 1.0, M + (j + PB) + (size_t)(j + PB) * ld,
                             ld, 0, 0, true, false);
+    }
+  }
+}
+// Panels wider than GPAK_PANEL_MID columns are factored in GPAK_PANEL_MID-column pieces with a K=MID update
+// of the rest of the panel in between (three-level blocking: 128 / MID / W).
+#define GPAK_PANEL_MID 512
+void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info) {
+  for (int j = J; j < J + W; j += GPAK_PANEL_MID) {
+    const int w = (J + W - j) < GPAK_PANEL_MID ? (J + W - j) : GPAK_PANEL_MID;
+    factor_panel_128(st, M, ld, Np, j, w, inv_base, info);
+    const int c0 = j + w, nct = (J + W - c0) / PB, mt = (Np - c0) / PB;
+    if (nct > 0 && mt > 0) {
+      const double *P = M + c0 + (size_t)j * ld;
+      gpak_launch_gemm_nt(st, mt, nct, w, -1.0, P, ld, P, ld, 1.0, M + c0 + (size_t)c0 * ld, ld, 0, 0, true, false);
     }
   }
 }

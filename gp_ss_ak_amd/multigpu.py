@@ -504,7 +504,7 @@ def bench(args):
                                    f"panel broadcast over RCCL", "N": N, "dist_mode": args.dist,
                        "nb_outer": gp.nb, "parallelism": f"block-column-cyclic x{world}"},
             "nlz": nlz,
-            "roofline": {"kernel": "gpak_gemm_nt_f64<true> (trailing update)", "bound": "mfma",
+            "roofline": {"kernel": "gpak_gemm_nt_f64_rs (trailing update)", "bound": "mfma",
                          "achieved": flops / (wall / args.steps) / 1e12 / world,
                          "peak": bench_mod.PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (wall / args.steps) / 1e12 / world / bench_mod.PEAK_F64_MFMA_TFLOPS,
