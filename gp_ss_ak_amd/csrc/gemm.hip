@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
 // latency (an L2-resident operand set runs no faster) but the barrier per stage and the LDS-DMA /
 // ds_read issue slots next to the MFMAs.
 // ---------------------------------------------------------------------------------------
-template <int RS_D, int RS_OCC>
+// TRAILING only names the instantiation (the bulk trailing update gets its own line in rocprofv3 statistics).
+template <int RS_D, int RS_OCC, bool TRAILING>
 __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double alpha, const double *A, long lda,
                                                                const double *B, long ldb, double beta, double *C,
                                                                long ldc, int rb0, int cb0, int lower_skip, int mt,
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w & 1, wc = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
+  if (!TRAILING) __builtin_amdgcn_s_setprio(2);  // panel-chain products go ahead of the bulk update's waves
   const int kstep0 = k0_by_row ? (rb0 + ti) * (TM / 4) : 0;
   const int nk = K / 4;
   // One 16-B load feeds TWO fragments: lane (l15, l4) fetches rows 32h + 2*l15, +1 of k-column 4s + l4 and
@@ -338,7 +340,7 @@ void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double
   const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
   const long nsuper = (long)SR * SC;
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
-  hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2>), grid, block, 0, st, K, -1.0, Pv, ldp, Pv, ldp, 1.0, Clocal, ldc,
+  hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, -1.0, Pv, ldp, Pv, ldp, 1.0, Clocal, ldc,
                      rt0, 0, 0, mt, nt, 0, P, rank, tpb, lt0);
 }
 
@@ -493,8 +495,11 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   // GPAK_GEMM=lds selects the LDS-staged kernel (kept for comparison); default: register streaming
   static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
-  if (!use_lds)
-    hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
+  if (!use_lds && trailing)
+    hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
+  else if (!use_lds)
+    hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
                        row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
   else if (trailing)
     hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,

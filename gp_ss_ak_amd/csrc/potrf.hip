@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
                                                           int col0, int *info) {
   __shared__ double T[36 * 256];
   __shared__ double dd[8][16];
+  // this workgroup is the serial link of the panel chain and shares its CU with two trailing-update
+  // waves per SIMD: let its instructions win the issue arbitration
+  __builtin_amdgcn_s_setprio(3);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   double *invT = inv + PB * PB;
