@@ -116,7 +116,8 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   int prio_lo = 0, prio_hi = 0;
   hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
   if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
-      (e = hipStreamCreateWithPriority(&ctx->stream_hi, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
+      (e = hipStreamCreateWithPriority(&ctx->stream_hi, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&ctx->stream_fs, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
     g_global_err = hipGetErrorString(e); delete ctx; return GPAK_EHIP;
   }
   for (int i = 0; i < 8; i++) hipEventCreate(&ctx->ev[i]);
@@ -145,6 +146,7 @@ void gpak_destroy(gpak_ctx *ctx) {
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   for (auto e : ctx->ev_sync) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream_hi);
+  hipStreamDestroy(ctx->stream_fs);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }

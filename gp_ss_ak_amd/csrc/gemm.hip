@@ -331,6 +331,90 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
 #undef RS_COL
 }
 
+// ---------------------------------------------------------------------------------------
+// Latency variant of the register-streaming kernel for SMALL tile grids (the panel chain of the
+// factorisation: panel solve, in-panel update, update of the next block column near the end).
+// A wave of the kernel above needs 16 MFMAs x 64 clk per k-step, i.e. >= 13.6 us for K=128 and
+// 54.6 us for K=512 however empty the GPU is.  Here a wave owns 32x32 (4 accumulators), eight waves
+// (2x4) cover 64 rows x 128 columns, and a 128x128 tile is spread over two workgroups / 16 waves:
+// a quarter of the MFMA chain per wave.  Plain (ti, tj) grid, no super-tiles (nothing to reuse).
+// ---------------------------------------------------------------------------------------
+#define RS32_D 8
+__global__ __launch_bounds__(512) void gpak_gemm_nt_f64_rs32(int K, double alpha, const double *A, long lda,
+                                                             const double *B, long ldb, double beta, double *C,
+                                                             long ldc, int rb0, int cb0, int lower_skip, int mt64,
+                                                             int nt, int k0_by_row) {
+  const int ti64 = blockIdx.x % mt64, tj = blockIdx.x / mt64;
+  const int ti = ti64 >> 1;  // 128-row tile index (skip rule and k-start are defined on 128-tiles)
+  if (tj >= nt) return;
+  if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
+  __builtin_amdgcn_s_setprio(2);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w & 1, wc = w >> 1;  // 2 x 4 waves of 32 x 32
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int kstep0 = k0_by_row ? (rb0 + ti) * (TM / 4) : 0;
+  const int n = K / 4 - kstep0;
+  const d2 *Ap = reinterpret_cast<const d2 *>(A + (size_t)ti64 * 64 + wr * 32 + 2 * l15 + (size_t)(4 * kstep0 + l4) * lda);
+  const d2 *Bp = reinterpret_cast<const d2 *>(B + (size_t)tj * TN + wc * 32 + 2 * l15 + (size_t)(4 * kstep0 + l4) * ldb);
+  const size_t sa = 2 * (size_t)lda, sb = 2 * (size_t)ldb;
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+  d2 ra[RS32_D], rbv[RS32_D];
+#define RS_LOAD(slot_) \
+  ra[slot_] = *Ap;     \
+  rbv[slot_] = *Bp;    \
+  Ap += sa;            \
+  Bp += sb;
+#define RS_MFMA(slot_)                                                                                       \
+  _Pragma("unroll") for (int mi = 0; mi < 2; mi++) _Pragma("unroll") for (int ni = 0; ni < 2; ni++)          \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(rbv[slot_][ni], ra[slot_][mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < RS32_D; s++) { RS_LOAD(s) }  // n >= 32 k-steps always
+  int g = 0;
+  for (; g + 2 * RS32_D <= n; g += RS32_D) {
+#pragma unroll
+    for (int s = 0; s < RS32_D; s++) {
+      RS_MFMA(s)
+      RS_LOAD(s)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int r = n - (g + RS32_D);
+#pragma unroll
+  for (int s = 0; s < RS32_D; s++) {
+    RS_MFMA(s)
+    if (s < r) { RS_LOAD(s) }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 0; s < RS32_D; s++)
+    if (s < r) { RS_MFMA(s) }
+#undef RS_LOAD
+#undef RS_MFMA
+  // in-place panel solve: the workgroup owns its 64 rows across all 128 columns, so one barrier orders
+  // every wave's operand reads before anybody's stores
+  if (A == C) __syncthreads();
+  // lane holds of tile (mi, ni): C row 2*l15 + mi, C columns 2(l4 + 4r) + ni of the wave's 32 x 32
+  double *Cg = C + (size_t)ti64 * 64 + wr * 32 + 2 * l15 + ((size_t)tj * TN + wc * 32) * ldc;
+#pragma unroll
+  for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      d2 *p = reinterpret_cast<d2 *>(Cg + (size_t)(2 * (l4 + 4 * r4) + ni) * ldc);
+      d2 v = {alpha * acc[0][ni][r4], alpha * acc[1][ni][r4]};
+      if (beta != 0.0) {
+        const d2 c = *p;
+        v.x = fma(alpha, acc[0][ni][r4], beta * c.x);
+        v.y = fma(alpha, acc[1][ni][r4], beta * c.y);
+      }
+      *p = v;
+    }
+}
+
 // Trailing update of ALL block columns a rank owns beyond local tile column lt0, in one launch:
 // C_local[rows >= rt0*128, local tile columns lt0..] -= Pv[rows] * Pv[global column rows]^T where
 // Pv is the panel addressed by global row (virtual base).  See the cyc_* comment in the kernel.
@@ -493,8 +577,23 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
     nsuper = (long)SR * SC;
   }
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
-  // GPAK_GEMM=lds selects the LDS-staged kernel (kept for comparison); default: register streaming
   static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
+  static const int small_max = getenv("GPAK_GEMM_SMALL") ? atoi(getenv("GPAK_GEMM_SMALL")) : 160;
+  long tiles = (long)mt * nt;
+  if (lower_skip) {  // valid lower 128-tiles
+    tiles = 0;
+    for (int tj = 0; tj < nt; tj++) {
+      int first = col_block0 + tj - row_block0;  // first ti with rb0+ti >= cb0+tj
+      if (first < 0) first = 0;
+      if (first < mt) tiles += mt - first;
+    }
+  }
+  if (!use_lds && tiles <= small_max) {
+    hipLaunchKernelGGL(gpak_gemm_nt_f64_rs32, dim3((unsigned)(2 * mt * nt)), dim3(512), 0, st, K, alpha, A, lda, B, ldb,
+                       beta, C, ldc, row_block0, col_block0, lower_skip ? 1 : 0, 2 * mt, nt, k0_by_row ? 1 : 0);
+    return;
+  }
+  // GPAK_GEMM=lds selects the LDS-staged kernel (kept for comparison); default: register streaming
   if (!use_lds && trailing)
     hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
                        row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);

@@ -332,6 +332,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   const int Np = ctx->Np;
   // without look-ahead everything is queued on the one main stream, in the classical order
   hipStream_t su = ctx->stream, sp = ctx->lookahead ? ctx->stream_hi : ctx->stream;
+  hipStream_t sf = ctx->lookahead ? ctx->stream_fs : ctx->stream;
   int NB = ctx->nb_outer;
   if (NB < PB) NB = PB;
   NB = NB / PB * PB;
@@ -339,13 +340,13 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   const int init = 0x7fffffff;
   GPAK_HIP(hipMemcpyAsync(ctx->dInfo, &init, sizeof(int), hipMemcpyHostToDevice, su));
 
-  while ((int)ctx->ev_sync.size() < 2 * nJ + 2) {
+  while ((int)ctx->ev_sync.size() < 2 * nJ + 3) {
     hipEvent_t e;
     GPAK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->ev_sync.push_back(e);
   }
   hipEvent_t *EF = ctx->ev_sync.data(), *EU = ctx->ev_sync.data() + nJ;
-  hipEvent_t Estart = ctx->ev_sync[2 * nJ], Eend = ctx->ev_sync[2 * nJ + 1];
+  hipEvent_t Estart = ctx->ev_sync[2 * nJ], Eend = ctx->ev_sync[2 * nJ + 1], Efs = ctx->ev_sync[2 * nJ + 2];
   // the panel stream starts after everything queued so far on the main stream (the fill)
   GPAK_HIP(hipEventRecord(Estart, su));
   GPAK_HIP(hipStreamWaitEvent(sp, Estart, 0));
@@ -357,11 +358,14 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
     const int J = b * NB;
     const int W = (Np - J) < NB ? (Np - J) : NB;
     factor_panel(ctx, sp, J, W);
-    // forward substitution of the right-hand side y/sn2 rides along on the panel stream: block
-    // column b of L is final here, and the solve touches only the two work vectors
-    if (ctx->fwd_in_factor)
-      gpak_launch_trsv_fwd_block(sp, Np, J, W, ctx->dM, ctx->ld, ctx->dInv, ctx->dWork, ctx->dWork + Np);
     GPAK_HIP(hipEventRecord(EF[b], sp));
+    // forward substitution of the right-hand side y/sn2 rides along: block column b of L is final
+    // here and the solve touches only the two work vectors.  It has its own stream so that its four
+    // small launches (~45 us) are not part of the serial panel chain
+    if (ctx->fwd_in_factor) {
+      if (sf != sp) GPAK_HIP(hipStreamWaitEvent(sf, EF[b], 0));
+      gpak_launch_trsv_fwd_block(sf, Np, J, W, ctx->dM, ctx->ld, ctx->dInv, ctx->dWork, ctx->dWork + Np);
+    }
     const int J1 = J + W;
     if (J1 >= Np) break;
     const int W1 = (Np - J1) < NB ? (Np - J1) : NB;
@@ -393,6 +397,10 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   int info = 0;
   GPAK_HIP(hipEventRecord(Eend, sp));
   GPAK_HIP(hipStreamWaitEvent(su, Eend, 0));
+  if (sf != su) {
+    GPAK_HIP(hipEventRecord(Efs, sf));
+    GPAK_HIP(hipStreamWaitEvent(su, Efs, 0));
+  }
   GPAK_HIP(hipMemcpyAsync(&info, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, su));
   GPAK_HIP(hipStreamSynchronize(su));
   ctx->times.trailing_flops = tflops;
