@@ -10,6 +10,9 @@
 //   * the f32 16x16x4 result layout is the standard one (col = lane&15, row = 4*(lane>>4)+reg);
 //     with the operand roles swapped as in gemm.hip a lane holds row (lane&15), columns
 //     4*(lane>>4) + reg of its 16x16 tile.
+#include <cstdlib>
+#include <cstring>
+
 #include "gpak_internal.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -96,13 +99,105 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f32(int K, float alpha, c
 #undef GPAK_COMPUTE32
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-streaming variant (the default, see gemm.hip): no LDS, no barriers.  One 16-B load per
+// operand and k-step feeds all FOUR of a wave's fragments on that side: lane (l15, l4) fetches rows
+// 4*l15 .. 4*l15+3 of k-column 4s + l4 and uses element i as its entry of MFMA tile i, i.e. tile i covers
+// the rows 4j + i, j = 0..15, of the wave's 64 (16 lanes = 256 B contiguous); the epilogue undoes the
+// permutation with 16-B accesses: of tile (mi, ni), register r, a lane holds C row 4*l15 + mi, C column
+// 16*l4 + 4*r + ni.
+// ---------------------------------------------------------------------------------------
+template <int RS_D>
+__global__ __launch_bounds__(256, 3) void gpak_gemm_nt_f32_rs(int K, float alpha, const float *A, long lda,
+                                                               const float *B, long ldb, float beta, float *C,
+                                                               long ldc, int mt, int nt) {
+  int ti, tj;
+  {
+    const int b = blockIdx.x, q = b >> 3;
+    const int slot = q & 63;
+    const int ssel = (q >> 6) * 8 + (b & 7);
+    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
+    const int sj = ssel / SR, si = ssel - sj * SR;
+    if (sj >= SC) return;
+    ti = si * 8 + (slot & 7);
+    tj = sj * 8 + (slot >> 3);
+    if (ti >= mt || tj >= nt) return;
+  }
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w & 1, wc = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const f4 *Ap = reinterpret_cast<const f4 *>(A + (size_t)ti * TM + wr * 64 + 4 * l15 + (size_t)l4 * lda);
+  const f4 *Bp = reinterpret_cast<const f4 *>(B + (size_t)tj * TN + wc * 64 + 4 * l15 + (size_t)l4 * ldb);
+  const size_t sa = (size_t)lda, sb = (size_t)ldb;  // 4 k-columns in 16-B units
+  f4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (f4){0.f, 0.f, 0.f, 0.f};
+  f4 ra[RS_D], rbv[RS_D];
+#define RS_LOAD(slot_) \
+  ra[slot_] = *Ap;     \
+  rbv[slot_] = *Bp;    \
+  Ap += sa;            \
+  Bp += sb;
+#define RS_MFMA(slot_)                                                                                      \
+  _Pragma("unroll") for (int mi = 0; mi < 4; mi++) _Pragma("unroll") for (int ni = 0; ni < 4; ni++)         \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(rbv[slot_][ni], ra[slot_][mi], acc[mi][ni], 0, 0, 0);
+  const int n = K / 4;  // >= 32 k-steps (K >= 128)
+#pragma unroll
+  for (int s = 0; s < RS_D; s++) { RS_LOAD(s) }
+  int g = 0;
+  for (; g + 2 * RS_D <= n; g += RS_D) {
+#pragma unroll
+    for (int s = 0; s < RS_D; s++) {
+      RS_MFMA(s)
+      RS_LOAD(s)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int r = n - (g + RS_D);
+#pragma unroll
+  for (int s = 0; s < RS_D; s++) {
+    RS_MFMA(s)
+    if (s < r) { RS_LOAD(s) }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 0; s < RS_D; s++)
+    if (s < r) { RS_MFMA(s) }
+#undef RS_LOAD
+#undef RS_MFMA
+  if (A == C) __syncthreads();  // in-place panel product: every wave's operand reads before anybody's stores
+  float *Cg = C + (size_t)ti * TM + wr * 64 + 4 * l15 + ((size_t)tj * TN + wc * 64 + 16 * l4) * ldc;
+#pragma unroll
+  for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      f4 *p = reinterpret_cast<f4 *>(Cg + (size_t)(4 * r4 + ni) * ldc);
+      f4 v = {alpha * acc[0][ni][r4], alpha * acc[1][ni][r4], alpha * acc[2][ni][r4], alpha * acc[3][ni][r4]};
+      if (beta != 0.f) {
+        const f4 c = *p;
+        v.x = fmaf(beta, c.x, v.x);
+        v.y = fmaf(beta, c.y, v.y);
+        v.z = fmaf(beta, c.z, v.z);
+        v.w = fmaf(beta, c.w, v.w);
+      }
+      *p = v;
+    }
+}
+
 void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha, const float *A, long lda,
                              const float *B, long ldb, float beta, float *C, long ldc) {
   if (mt <= 0 || nt <= 0) return;
   const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
   const long nsuper = (long)SR * SC;
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
-  hipLaunchKernelGGL(gpak_gemm_nt_f32, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+  static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
+  if (use_lds)
+    hipLaunchKernelGGL(gpak_gemm_nt_f32, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+  else
+    hipLaunchKernelGGL(gpak_gemm_nt_f32_rs<8>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
 }
 
 // ---- fp32 images of the fp64 factor ---------------------------------------------------------
