@@ -25,7 +25,7 @@ int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap) {
   if (p.cap >= cap) return GPAK_OK;
   free_points(p);
   double *base = nullptr;
-  if (hipMalloc(&base, sizeof(double) * 4 * GPAK_MAX_TERMS * (size_t)cap) != hipSuccess) {
+  if (hipMalloc(&base, sizeof(double) * GPAK_PT * GPAK_MAX_TERMS * (size_t)cap) != hipSuccess) {
     ctx->err = "hipMalloc(points) failed";
     return GPAK_ENOMEM;
   }
@@ -60,7 +60,7 @@ void gpak_build_siginv(const double *e, double *A) {
 
 // pooled mean of X1 u X2 exactly as Kernel.cpp:1391-1392 computes it
 void gpak_pooled_mean(const double *s1, long n, const double *s2, long m, double *mu) {
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < 4; k++) {  // s1, s2, mu hold four column sums (the 4th is 0 for 3-D inputs)
     double mX1 = (double)n / (double)(n + m) * s1[k] / (double)n;
     mu[k] = (double)m / (double)(n + m) * s2[k] / (double)m + mX1;
   }
@@ -170,7 +170,8 @@ int gpak_set_option(gpak_ctx *ctx, int option, long value) {
 
 int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d) {
   if (!ctx || !X || !y || N <= 0) return GPAK_EINVAL;
-  if (d != 3) { ctx->err = "HIP path handles 3-D inputs (d=4 rock-type column: SURVEY.md Q7, not built)"; return GPAK_ENOTIMPL; }
+  // d = 3: x, y, z; d = 4: + rock-type column with its own inverse width (Kernel.cpp:1411-1424)
+  if (d != 3 && d != 4) { ctx->err = "inputs must have 3 or 4 columns"; return GPAK_ENOTIMPL; }
   GPAK_HIP(hipSetDevice(ctx->device));
   release_train(ctx);
   const int Np = round_up(N, GPAK_TILE);
@@ -179,13 +180,14 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
   const long ld = Np + pad;
   ctx->N = N; ctx->Np = Np; ctx->ld = (int)ld; ctx->d = d;
   ctx->hX.assign(X, X + (size_t)N * d);
-  for (int k = 0; k < 3; k++) {
+  ctx->xsum[3] = 0.0;
+  for (int k = 0; k < d; k++) {
     double s = 0.0;
     for (int i = 0; i < N; i++) s += X[i + (size_t)k * N];
     ctx->xsum[k] = s;
   }
   const int T = Np / GPAK_TILE;
-  if (hipMalloc(&ctx->dX, sizeof(double) * 3 * (size_t)Np) != hipSuccess ||
+  if (hipMalloc(&ctx->dX, sizeof(double) * 4 * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dy, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dM, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
       hipMalloc(&ctx->dInv, sizeof(double) * (size_t)T * 2 * GPAK_TILE * GPAK_TILE) != hipSuccess ||
@@ -198,10 +200,10 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
   }
   int rc = gpak_alloc_points(ctx, ctx->U, Np);
   if (rc) return rc;
-  GPAK_HIP(hipMemsetAsync(ctx->dX, 0, sizeof(double) * 3 * (size_t)Np, ctx->stream));
+  GPAK_HIP(hipMemsetAsync(ctx->dX, 0, sizeof(double) * 4 * (size_t)Np, ctx->stream));
   GPAK_HIP(hipMemsetAsync(ctx->dy, 0, sizeof(double) * (size_t)Np, ctx->stream));
   GPAK_HIP(hipMemsetAsync(ctx->dAlpha, 0, sizeof(double) * (size_t)Np, ctx->stream));
-  for (int k = 0; k < 3; k++)
+  for (int k = 0; k < d; k++)
     GPAK_HIP(hipMemcpyAsync(ctx->dX + (size_t)k * Np, X + (size_t)k * N, sizeof(double) * N,
                             hipMemcpyHostToDevice, ctx->stream));
   GPAK_HIP(hipMemcpyAsync(ctx->dy, y, sizeof(double) * N, hipMemcpyHostToDevice, ctx->stream));
@@ -223,6 +225,7 @@ int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2
   ctx->kinds[0] = GPAK_KERN_EXPANS;
   ctx->kp.nterms = 1;
   gpak_build_siginv(expans, ctx->kp.term[0].A);
+  ctx->kp.term[0].a33 = expans[7];  // InversewidthR: lambda(3,3) for a 4th input column (Kernel.cpp:1421-1424)
   ctx->kp.term[0].var2 = expans[6] * expans[6];
   ctx->kp.term[0].iw = 0.0;
   ctx->kp.term[0].profile = GPAK_PROFILE_EXPSQRT;
@@ -254,17 +257,18 @@ int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *p
     KernTerm &T = kp.term[t];
     if (kinds[t] == GPAK_KERN_EXPANS) {
       gpak_build_siginv(p, T.A);
+      T.a33 = p[7];
       T.var2 = p[6] * p[6]; T.profile = GPAK_PROFILE_EXPSQRT;
       memcpy(ctx->expans, p, sizeof(double) * 8);  // the (single) ExpAns child, wherever it sits
       p += 8;
     } else if (kinds[t] == GPAK_KERN_EXP) {   // {Hayper_Euc_Exp, Sigma_Exp}, Kernel.cpp:576-600
       const double s = 1.0 / p[0];             // mlA: X * hyp^-2 on one side == both sides scaled by 1/hyp
-      T.A[0] = T.A[4] = T.A[8] = s;
+      T.A[0] = T.A[4] = T.A[8] = T.a33 = s;  // EuclDist treats every input column alike (Kernel.cpp:1356-1362)
       T.var2 = p[1] * p[1]; T.profile = GPAK_PROFILE_EXPSQRT;
       p += 2;
     } else if (kinds[t] == GPAK_KERN_RBF) {   // {Hayper_Euc_RBF, inverseWidth_RBF, Sigma_RBF}, Kernel.cpp:411-428
       const double s = 1.0 / p[0];
-      T.A[0] = T.A[4] = T.A[8] = s;
+      T.A[0] = T.A[4] = T.A[8] = T.a33 = s;
       T.iw = p[1]; T.var2 = p[2] * p[2]; T.profile = GPAK_PROFILE_RBF;
       p += 3;
     } else { ctx->err = "unknown kernel kind"; return GPAK_EINVAL; }
@@ -291,6 +295,7 @@ int gpak_ensure_U(gpak_ctx *ctx) {
   if (!ctx->have_params) { ctx->err = "no parameters (gpak_set_params)"; return GPAK_ESTATE; }
   if (ctx->U.n == ctx->N) return GPAK_OK;
   gpak_pooled_mean(ctx->xsum, ctx->N, ctx->xsum, ctx->N, ctx->kp.mu);
+  ctx->kp.d = ctx->d;
   gpak_launch_transform(ctx->stream, ctx->dX, ctx->Np, ctx->N, ctx->kp, ctx->U);
   return GPAK_OK;
 }
@@ -415,23 +420,24 @@ int gpak_gram(gpak_ctx *ctx, double *K_host, double *D2_host) {
 int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int m, int d, double *K_host,
                    double *D2_host) {
   if (!ctx || !X1 || !X2 || n <= 0 || m <= 0) return GPAK_EINVAL;
-  if (d != 3) { ctx->err = "HIP path handles 3-D inputs"; return GPAK_ENOTIMPL; }
+  if (d != 3 && d != 4) { ctx->err = "inputs must have 3 or 4 columns"; return GPAK_ENOTIMPL; }
   if (!ctx->have_params) { ctx->err = "no parameters (gpak_set_params)"; return GPAK_ESTATE; }
   GPAK_HIP(hipSetDevice(ctx->device));
   const int np = round_up(n, GPAK_TILE), mp = round_up(m, GPAK_TILE);
-  double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
-  for (int k = 0; k < 3; k++) {
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int k = 0; k < d; k++) {
     for (int i = 0; i < n; i++) s1[k] += X1[i + (size_t)k * n];
     for (int i = 0; i < m; i++) s2[k] += X2[i + (size_t)k * m];
   }
   KernParams kp = ctx->kp;
+  kp.d = d;
   gpak_pooled_mean(s1, n, s2, m, kp.mu);
   if (!(X1[0] == X2[0] && n == m)) kp.white = 0.0;  // Kern_White::computeK, Kernel.cpp:260-262
   DevPoints P, Q;
   double *dx = nullptr, *dK = nullptr, *dD2 = nullptr;
   int rc = gpak_alloc_points(ctx, P, np);
   if (!rc) rc = gpak_alloc_points(ctx, Q, mp);
-  if (!rc && (hipMalloc(&dx, sizeof(double) * 3 * (size_t)(np + mp)) != hipSuccess ||
+  if (!rc && (hipMalloc(&dx, sizeof(double) * 4 * (size_t)(np + mp)) != hipSuccess ||
               hipMalloc(&dK, sizeof(double) * (size_t)np * mp) != hipSuccess ||
               (D2_host && hipMalloc(&dD2, sizeof(double) * (size_t)np * mp) != hipSuccess))) {
     ctx->err = "device allocation failed in gpak_compute_k";
@@ -439,9 +445,9 @@ int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int
   }
   if (!rc) {
     hipStream_t st = ctx->stream;
-    hipMemsetAsync(dx, 0, sizeof(double) * 3 * (size_t)(np + mp), st);
-    double *dx2 = dx + 3 * (size_t)np;
-    for (int k = 0; k < 3; k++) {
+    hipMemsetAsync(dx, 0, sizeof(double) * 4 * (size_t)(np + mp), st);
+    double *dx2 = dx + 4 * (size_t)np;
+    for (int k = 0; k < d; k++) {
       hipMemcpyAsync(dx + (size_t)k * np, X1 + (size_t)k * n, sizeof(double) * n, hipMemcpyHostToDevice, st);
       hipMemcpyAsync(dx2 + (size_t)k * mp, X2 + (size_t)k * m, sizeof(double) * m, hipMemcpyHostToDevice, st);
     }
@@ -520,7 +526,7 @@ int gpak_nlz_terms(gpak_ctx *ctx, double *quad, double *sumlp, double *logdet) {
 
 int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, double *var, int compat_flags) {
   if (!ctx || !Xte || !mean || M <= 0) return GPAK_EINVAL;
-  if (d != 3) { ctx->err = "HIP path handles 3-D inputs"; return GPAK_ENOTIMPL; }
+  if (d != ctx->d) { ctx->err = "test points must have as many columns as the training set"; return GPAK_EINVAL; }
   // _postVar calls logLikelihood() (GP_Utils.cpp:980); _postMean calls updateAlpha() (:961)
   int rc = ensure_nlz(ctx);
   if (rc) return rc;

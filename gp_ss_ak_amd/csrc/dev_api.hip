@@ -24,6 +24,7 @@ static KernParams make_kp(const double *expans, double bias, int mode, const dou
   kp.term[0].var2 = expans[6] * expans[6];
   kp.term[0].profile = GPAK_PROFILE_EXPSQRT;
   for (int k = 0; k < 3; k++) kp.mu[k] = mu ? mu[k] : 0.0;
+  kp.d = 3;  // the distributed path handles 3-D inputs
   kp.bias = bias;
   kp.mode = mode;
   return kp;

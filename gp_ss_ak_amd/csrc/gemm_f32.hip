@@ -222,12 +222,13 @@ void gpak_launch_vec_to_f32(hipStream_t st, const double *in, size_t n, float *o
 
 // ---- fp32 cross-kernel fill (test-major batch) and row sums of squares ------------------------
 // distance in fp64 from the fp64 coordinates (three subtractions), profile sqrt/exp in fp32
-#define PARR32(base, cap, t, c) ((base) + (size_t)(4 * (t) + (c)) * (cap))
+// components 0..2 and the 4th input column (array 4 of the point layout; zero for 3-D inputs)
+#define PARR32(base, cap, t, c) GPAK_PARR(base, cap, t, (c) < 3 ? (c) : 4)
 __global__ __launch_bounds__(256) void gpak_fill_f32(const double *__restrict__ P, int capP, int nP,
                                                       const double *__restrict__ Q, int capQ, int nQ, KernParams kp,
                                                       float *__restrict__ C, long ld) {
   const int row0 = blockIdx.x * 128, col0 = blockIdx.y * 64;
-  __shared__ double q[GPAK_MAX_TERMS][3][64];
+  __shared__ double q[GPAK_MAX_TERMS][4][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int nterms = kp.nterms;
   if (t < 64) {
@@ -235,24 +236,24 @@ __global__ __launch_bounds__(256) void gpak_fill_f32(const double *__restrict__ 
     const bool ok = j < nQ;
     for (int m = 0; m < nterms; m++)
 #pragma unroll
-      for (int c = 0; c < 3; c++) q[m][c][t] = ok ? PARR32(Q, capQ, m, c)[j] : 0.0;
+      for (int c = 0; c < 4; c++) q[m][c][t] = ok ? PARR32(Q, capQ, m, c)[j] : 0.0;
   }
   const int r = row0 + 2 * lane;
-  double2 a[GPAK_MAX_TERMS][3];
+  double2 a[GPAK_MAX_TERMS][4];
   for (int m = 0; m < nterms; m++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) a[m][c] = *reinterpret_cast<const double2 *>(PARR32(P, capP, m, c) + r);
+    for (int c = 0; c < 4; c++) a[m][c] = *reinterpret_cast<const double2 *>(PARR32(P, capP, m, c) + r);
   __syncthreads();
 #pragma unroll 2
   for (int c = 0; c < 16; c++) {
     const int jl = w + 4 * c, j = col0 + jl;
     float k0 = (float)kp.bias, k1 = (float)kp.bias;
     for (int m = 0; m < nterms; m++) {
-      const double b0 = q[m][0][jl], b1 = q[m][1][jl], b2 = q[m][2][jl];
-      double dx = a[m][0].x - b0, dy = a[m][1].x - b1, dz = a[m][2].x - b2;
-      const float d0 = (float)(dx * dx + dy * dy + dz * dz);
-      dx = a[m][0].y - b0; dy = a[m][1].y - b1; dz = a[m][2].y - b2;
-      const float d1 = (float)(dx * dx + dy * dy + dz * dz);
+      const double b0 = q[m][0][jl], b1 = q[m][1][jl], b2 = q[m][2][jl], b3 = q[m][3][jl];
+      double dx = a[m][0].x - b0, dy = a[m][1].x - b1, dz = a[m][2].x - b2, dr = a[m][3].x - b3;
+      const float d0 = (float)(dx * dx + dy * dy + dz * dz + dr * dr);
+      dx = a[m][0].y - b0; dy = a[m][1].y - b1; dz = a[m][2].y - b2; dr = a[m][3].y - b3;
+      const float d1 = (float)(dx * dx + dy * dy + dz * dz + dr * dr);
       const float v2 = (float)kp.term[m].var2;
       if (kp.term[m].profile == GPAK_PROFILE_RBF) {
         const float hw = -0.5f * (float)kp.term[m].iw;

@@ -20,6 +20,8 @@
 #define GPAK_PROFILE_RBF 1
 struct KernTerm {
   double A[9];   // column-major 3x3 metric factor
+  double a33;    // factor of a 4th input column (rock type): InversewidthR for ExpAns
+                 // (Kernel.cpp:1411-1424, A(3,3) = L_r), the isotropic scale for Exp / RBF (EuclDist)
   double var2;   // Sigma^2
   double iw;     // inverseWidth_RBF (profile 1 only)
   int profile;
@@ -27,14 +29,18 @@ struct KernTerm {
 struct KernParams {
   KernTerm term[GPAK_MAX_TERMS];
   int nterms;
-  double mu[3];  // pooled mean used for centring (Kernel.cpp:1391-1397)
+  double mu[4];  // pooled mean used for centring (Kernel.cpp:1391-1397)
+  int d;         // input columns: 3, or 4 (x, y, z, rock type)
   double bias;   // Kern_Bias Sigma_Bias (Kernel.cpp:366), added to every entry
   double white;  // Kern_White Sigma_White (Kernel.cpp:256-263), added where i == j of the same set
   int mode;      // GPAK_DIST_*
 };
 
 // A transformed point set on the device: for each term u = (x - mu) A_t, SoA, plus |u|^2:
-// array c (0..2 = u0,u1,u2; 3 = |u|^2) of term t is base + (4 t + c) * cap.
+// array c (0..2 = u0,u1,u2; 3 = |u|^2; 4 = u3, the transformed 4th column, zero for 3-D inputs) of
+// term t is base + (GPAK_PT * t + c) * cap.
+#define GPAK_PT 5
+#define GPAK_PARR(base, cap, t, c) ((base) + (size_t)(GPAK_PT * (t) + (c)) * (cap))
 struct DevPoints {
   double *base = nullptr;
   int n = 0;    // valid points
@@ -51,10 +57,10 @@ struct gpak_ctx {
 
   // training set
   int N = 0, Np = 0, ld = 0, d = 0;
-  double *dX = nullptr;      // N x 3 raw coordinates, SoA with stride Np
+  double *dX = nullptr;      // raw input columns (3 or 4), SoA with stride Np (4 arrays, the 4th zero for d = 3)
   double *dy = nullptr;      // Np (padded with 0)
   std::vector<double> hX;    // host copy of X (col-major N x d), for pooled means
-  double xsum[3] = {0, 0, 0};
+  double xsum[4] = {0, 0, 0, 0};
 
   // parameters
   bool have_params = false;
@@ -85,7 +91,7 @@ struct gpak_ctx {
 
   // prediction buffers (grown on demand, kept across calls)
   DevPoints Upred, Tq;       // train / test-batch points centred on the pooled train+test mean
-  double *dXte = nullptr;    // 3 x pred_cap raw test coordinates (SoA)
+  double *dXte = nullptr;    // 4 x pred_cap raw test columns (SoA)
   double *dWt = nullptr;     // pred_cap x Np cross-kernel, test-major (transposed kX)
   double *dPv = nullptr;     // 2 x pred_cap: mean, sum of squares
   double *dPart = nullptr;   // 64 x pred_cap partial sums

@@ -22,7 +22,7 @@
 #define PB 128
 #define GT_ROWS 128
 #define GT_COLS 64
-#define NSUM 15  // 9 shared/ExpAns sums + 2 per stationary term for the Exp / RBF children
+#define NSUM 16  // 9 shared/ExpAns sums + 2 per stationary term for the Exp / RBF children + the rock-type sum
 
 struct GradConsts {
   double M[6][6];   // S % S_p, symmetric 3x3 stored as {00,01,02,11,12,22}, p = 0..5
@@ -45,14 +45,17 @@ __global__ void gpak_identity_f64(double *W, long ld, int n) {
 //   [0..5] sum Rm * Di2^(p)   [6] sum QW * exp(-sqrt(D_expans))   [7] sum Q * K   [8] trace(QW)
 //   [9+2t], [10+2t]  the two sums of stationary term t when it is an Exp or RBF child; those
 //   children work on GP_utils' member D2 = the SUM of the children's D2 (Kernel.cpp:151, 491-540, 644-693)
-#define PARRG(base, cap, t, c) ((base) + (size_t)(4 * (t) + (c)) * (cap))
+//   [15] sum exp(-sqrt(D_expans)) * (x4_i - x4_j)^2 for 4-column inputs (Kernel.cpp:1246-1255: the weight is
+//        KD2, not R -- RColon still holds KD2 from the Sigma block, reproduced as written)
+#define PARRG GPAK_PARR
 __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
     const double *__restrict__ U, int cap, const double *__restrict__ x0, const double *__restrict__ x1,
-    const double *__restrict__ x2, const double *__restrict__ alpha, const double *__restrict__ Binv, long ld,
-    int N, KernParams kp, GradConsts gc, double *__restrict__ part) {
+    const double *__restrict__ x2, const double *__restrict__ x3, const double *__restrict__ alpha,
+    const double *__restrict__ Binv, long ld, int N, KernParams kp, GradConsts gc, double *__restrict__ part) {
   const int row0 = blockIdx.x * GT_ROWS, col0 = blockIdx.y * GT_COLS;
   const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-  __shared__ double cq[GPAK_MAX_TERMS][4][GT_COLS];  // transformed column points, per term
+  __shared__ double cq[GPAK_MAX_TERMS][GPAK_PT][GT_COLS];  // transformed column points, per term
+  __shared__ double cx3[GT_COLS];                    // raw 4th column of the column points (0 for 3-D)
   __shared__ double cal[GT_COLS];                    // alpha of the column points
   __shared__ double cm[6][3][GT_COLS];               // M_p x_j
   __shared__ double ca[6][GT_COLS];                  // a_j^(p)
@@ -68,8 +71,9 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
       const bool ok = j < N;
       for (int m = 0; m < nterms; m++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) cq[m][c][t] = ok ? PARRG(U, cap, m, c)[j] : 0.0;
+        for (int c = 0; c < GPAK_PT; c++) cq[m][c][t] = ok ? PARRG(U, cap, m, c)[j] : 0.0;
       cal[t] = ok ? alpha[j] : 0.0;
+      cx3[t] = (ok && x3) ? x3[j] : 0.0;
       const double a = ok ? x0[j] : 0.0, b = ok ? x1[j] : 0.0, c = ok ? x2[j] : 0.0;
 #pragma unroll
       for (int p = 0; p < 6; p++) {
@@ -82,14 +86,15 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
     }
     __syncthreads();
     const int r = row0 + 2 * lane;
-    double pu[2][GPAK_MAX_TERMS][4], px[2][3], pa[2][6], pal[2];
+    double pu[2][GPAK_MAX_TERMS][GPAK_PT], px[2][3], pa[2][6], pal[2], px3[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int i = r + h;
       const bool ok = i < N;
       for (int m = 0; m < nterms; m++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) pu[h][m][c] = ok ? PARRG(U, cap, m, c)[i] : 0.0;
+        for (int c = 0; c < GPAK_PT; c++) pu[h][m][c] = ok ? PARRG(U, cap, m, c)[i] : 0.0;
+      px3[h] = (ok && x3) ? x3[i] : 0.0;
       px[h][0] = ok ? x0[i] : 0.0; px[h][1] = ok ? x1[i] : 0.0; px[h][2] = ok ? x2[i] : 0.0;
       pal[h] = ok ? alpha[i] : 0.0;
 #pragma unroll
@@ -114,9 +119,11 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
           double d2;
           if (gc.mode == GPAK_DIST_DIRECT) {
             const double a = pu[h][m][0] - cq[m][0][jl], b = pu[h][m][1] - cq[m][1][jl], cc = pu[h][m][2] - cq[m][2][jl];
-            d2 = a * a + b * b + cc * cc;
+            const double e4 = pu[h][m][4] - cq[m][4][jl];
+            d2 = a * a + b * b + cc * cc + e4 * e4;
           } else {
-            const double dot = pu[h][m][0] * cq[m][0][jl] + pu[h][m][1] * cq[m][1][jl] + pu[h][m][2] * cq[m][2][jl];
+            const double dot = pu[h][m][0] * cq[m][0][jl] + pu[h][m][1] * cq[m][1][jl] + pu[h][m][2] * cq[m][2][jl] +
+                               pu[h][m][4] * cq[m][4][jl];
             d2 = pu[h][m][3] + cq[m][3][jl] - 2.0 * dot;
             d2 = d2 < 0.0 ? 0.0 : d2;
           }
@@ -140,6 +147,8 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
             acc[p] = fma(wgt * rm, di2, acc[p]);
           }
           acc[6] = fma(wgt * qw, ek, acc[6]);                       // :1239-1241
+          const double dx4 = px3[h] - cx3[jl];
+          acc[15] = fma(wgt * ek, dx4 * dx4, acc[15]);              // :1246-1253 (Di2_R = 2 dx4^2)
         }
 #pragma unroll
         for (int m = 0; m < GPAK_MAX_TERMS; m++) {
@@ -342,7 +351,8 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng) {
   int rc = gpak_ensure_U(ctx);
   if (rc) return rc;
   hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, ctx->U.base, ctx->U.cap, ctx->dX, ctx->dX + Np,
-                     ctx->dX + 2 * (size_t)Np, ctx->dAlpha, ctx->dBinv, ld, N, ctx->kp, gc, ctx->dGpart);
+                     ctx->dX + 2 * (size_t)Np, ctx->d == 4 ? ctx->dX + 3 * (size_t)Np : (const double *)nullptr,
+                     ctx->dAlpha, ctx->dBinv, ld, N, ctx->kp, gc, ctx->dGpart);
   hipLaunchKernelGGL(gpak_grad_reduce_f64, dim3(NSUM), dim3(256), 0, st, ctx->dGpart, (int)nblocks, ctx->dRed + 8);
   hipLaunchKernelGGL(gpak_lpdhyp_f64, dim3(1), dim3(1024), 0, st, N, ctx->dy, ctx->dF, ctx->sn2, ctx->dRed + 8 + NSUM);
   double red[NSUM + 1];
@@ -359,7 +369,8 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng) {
     if (ctx->kinds[t] == GPAK_KERN_EXPANS) {
       for (int p = 0; p < 6; p++) g[go + p] = red[p];            // Kernel.cpp:1195-1233
       g[go + 6] = 2.0 * red[6] * ctx->expans[6];                 // :1241-1242
-      g[go + 7] = 0.0;                                           // :1256-1257 (3-D)
+      // :1246-1257: 0 for 3-D inputs; with a rock-type column -2 * sum(KD2 % Di2_R) / N, Di2_R = 2 dx4^2
+      g[go + 7] = ctx->d == 4 ? -4.0 * red[15] / (double)N : 0.0;
       go += 8;
     } else if (ctx->kinds[t] == GPAK_KERN_EXP) {                 // Kernel.cpp:671-690
       g[go] = T.var2 * A;

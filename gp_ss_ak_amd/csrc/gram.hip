@@ -7,7 +7,7 @@
 // exactly once.  HBM-write bound: 8 bytes per element written, 32 bytes per point and term read.
 #include "gpak_internal.h"
 
-#define PARR(base, cap, t, c) ((base) + (size_t)(4 * (t) + (c)) * (cap))
+#define PARR GPAK_PARR
 
 // ---------------------------------------------------------------------------------------
 // u = (x - mu) A_t  (Kernel.cpp:1393-1427 / :1356-1362), s = |u|^2 ("sum(X1 % X1, 1)", :1431)
@@ -16,17 +16,20 @@ __global__ void gpak_transform_f64(const double *__restrict__ x, int xs, int n, 
                                    double *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
-  double c0 = 0, c1 = 0, c2 = 0;
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   if (i < n) {
     c0 = x[i] - kp.mu[0]; c1 = x[(size_t)xs + i] - kp.mu[1]; c2 = x[2 * (size_t)xs + i] - kp.mu[2];
+    if (kp.d == 4) c3 = x[3 * (size_t)xs + i] - kp.mu[3];
   }
   for (int t = 0; t < kp.nterms; t++) {
     const double *A = kp.term[t].A;
     const double a = c0 * A[0] + c1 * A[1] + c2 * A[2];
     const double b = c0 * A[3] + c1 * A[4] + c2 * A[5];
     const double c = c0 * A[6] + c1 * A[7] + c2 * A[8];
+    const double e = c3 * kp.term[t].a33;  // Rot(3,3) = 1, lambda(3,3) = L_r (Kernel.cpp:1411-1424); 0 for 3-D
     PARR(out, cap, t, 0)[i] = a; PARR(out, cap, t, 1)[i] = b; PARR(out, cap, t, 2)[i] = c;
-    PARR(out, cap, t, 3)[i] = a * a + b * b + c * c;
+    PARR(out, cap, t, 3)[i] = a * a + b * b + c * c + e * e;
+    PARR(out, cap, t, 4)[i] = e;
   }
 }
 
@@ -38,13 +41,13 @@ void gpak_launch_transform(hipStream_t st, const double *x, int xs, int n, const
 }
 
 // D2 (Kernel.cpp:1431-1434 / :1365-1367, or the cancellation-free equivalent)
-__device__ __forceinline__ double gpak_d2(double p0, double p1, double p2, double ps, double q0, double q1,
-                                          double q2, double qs, int mode) {
+__device__ __forceinline__ double gpak_d2(double p0, double p1, double p2, double ps, double p3, double q0,
+                                          double q1, double q2, double qs, double q3, int mode) {
   if (mode == GPAK_DIST_DIRECT) {
-    double a = p0 - q0, b = p1 - q1, c = p2 - q2;
-    return a * a + b * b + c * c;
+    double a = p0 - q0, b = p1 - q1, c = p2 - q2, e = p3 - q3;
+    return a * a + b * b + c * c + e * e;  // e == 0 for 3-D inputs: the value is unchanged bit for bit
   }
-  double dot = p0 * q0 + p1 * q1 + p2 * q2;
+  double dot = p0 * q0 + p1 * q1 + p2 * q2 + p3 * q3;
   double v = ps + qs - 2.0 * dot;
   return v < 0.0 ? 0.0 : v;
 }
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void gpak_fill_f64(const double *__restrict__ 
   if (lower_only && row0 + FILL_ROWS <= col0 + col_off) return;
   // NT = 1: the reference's default composition (one ExpAns term) with everything unrolled;
   // NT = 0: any number of terms at run time
-  __shared__ double q[NT ? NT : GPAK_MAX_TERMS][4][FILL_COLS];
+  __shared__ double q[NT ? NT : GPAK_MAX_TERMS][GPAK_PT][FILL_COLS];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int nterms = NT ? NT : kp.nterms;
   if (t < FILL_COLS) {
@@ -78,15 +81,15 @@ __global__ __launch_bounds__(256) void gpak_fill_f64(const double *__restrict__ 
     const bool ok = j < nQ;
     for (int m = 0; m < nterms; m++)
 #pragma unroll
-      for (int c = 0; c < 4; c++) q[m][c][t] = ok ? PARR(Q, capQ, m, c)[j] : 0.0;
+      for (int c = 0; c < GPAK_PT; c++) q[m][c][t] = ok ? PARR(Q, capQ, m, c)[j] : 0.0;
   }
   const int r = row0 + 2 * lane;
-  double2 a[NT ? NT : GPAK_MAX_TERMS][4];
+  double2 a[NT ? NT : GPAK_MAX_TERMS][GPAK_PT];
 #pragma unroll
   for (int m = 0; m < (NT ? NT : GPAK_MAX_TERMS); m++)
     if (m < nterms) {
 #pragma unroll
-      for (int c = 0; c < 4; c++) a[m][c] = *reinterpret_cast<const double2 *>(PARR(P, capP, m, c) + r);
+      for (int c = 0; c < GPAK_PT; c++) a[m][c] = *reinterpret_cast<const double2 *>(PARR(P, capP, m, c) + r);
     }
   __syncthreads();
 #pragma unroll 4
@@ -96,10 +99,10 @@ __global__ __launch_bounds__(256) void gpak_fill_f64(const double *__restrict__ 
 #pragma unroll
     for (int m = 0; m < (NT ? NT : GPAK_MAX_TERMS); m++) {
       if (m >= nterms) break;
-      const double e0 = gpak_d2(a[m][0].x, a[m][1].x, a[m][2].x, a[m][3].x, q[m][0][jl], q[m][1][jl], q[m][2][jl],
-                                q[m][3][jl], kp.mode);
-      const double e1 = gpak_d2(a[m][0].y, a[m][1].y, a[m][2].y, a[m][3].y, q[m][0][jl], q[m][1][jl], q[m][2][jl],
-                                q[m][3][jl], kp.mode);
+      const double e0 = gpak_d2(a[m][0].x, a[m][1].x, a[m][2].x, a[m][3].x, a[m][4].x, q[m][0][jl], q[m][1][jl],
+                                q[m][2][jl], q[m][3][jl], q[m][4][jl], kp.mode);
+      const double e1 = gpak_d2(a[m][0].y, a[m][1].y, a[m][2].y, a[m][3].y, a[m][4].y, q[m][0][jl], q[m][1][jl],
+                                q[m][2][jl], q[m][3][jl], q[m][4][jl], kp.mode);
       k0 += gpak_profile(e0, kp.term[m]);
       k1 += gpak_profile(e1, kp.term[m]);
       d0 += e0; d1 += e1;   // HybKerns sums the children's D2 too (Kernel.cpp:151)
@@ -142,16 +145,16 @@ __global__ __launch_bounds__(256) void gpak_kmatvec_part_f64(const double *__res
                                                               KernParams kp, double *__restrict__ part,
                                                               int part_ld) {
   constexpr int MT = NT ? NT : GPAK_MAX_TERMS;
-  __shared__ double sp[MT * 4 + 1][KMV_CHUNK];
+  __shared__ double sp[MT * GPAK_PT + 1][KMV_CHUNK];
   const int nterms = NT ? NT : kp.nterms;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const bool ok = j < nQ;
-  double b[MT][4];
+  double b[MT][GPAK_PT];
 #pragma unroll
   for (int m = 0; m < MT; m++)
     if (m < nterms) {
 #pragma unroll
-      for (int c = 0; c < 4; c++) b[m][c] = ok ? PARR(Q, capQ, m, c)[j] : 0.0;
+      for (int c = 0; c < GPAK_PT; c++) b[m][c] = ok ? PARR(Q, capQ, m, c)[j] : 0.0;
     }
   const int i_begin = blockIdx.y * per_split;
   const int i_end = min(nP, i_begin + per_split);
@@ -162,8 +165,8 @@ __global__ __launch_bounds__(256) void gpak_kmatvec_part_f64(const double *__res
     __syncthreads();
     for (int m = 0; m < nterms; m++)
 #pragma unroll
-      for (int c = 0; c < 4; c++) sp[4 * m + c][threadIdx.x] = v ? PARR(P, capP, m, c)[p_off + i] : 0.0;
-    sp[MT * 4][threadIdx.x] = v ? w[i] : 0.0;  // zero weight masks the tail
+      for (int c = 0; c < GPAK_PT; c++) sp[GPAK_PT * m + c][threadIdx.x] = v ? PARR(P, capP, m, c)[p_off + i] : 0.0;
+    sp[MT * GPAK_PT][threadIdx.x] = v ? w[i] : 0.0;  // zero weight masks the tail
     __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < KMV_CHUNK; k++) {
@@ -171,11 +174,12 @@ __global__ __launch_bounds__(256) void gpak_kmatvec_part_f64(const double *__res
 #pragma unroll
       for (int m = 0; m < MT; m++) {
         if (m >= nterms) break;
-        const double d2 = gpak_d2(sp[4 * m][k], sp[4 * m + 1][k], sp[4 * m + 2][k], sp[4 * m + 3][k], b[m][0], b[m][1],
-                                  b[m][2], b[m][3], kp.mode);
+        const double d2 = gpak_d2(sp[GPAK_PT * m][k], sp[GPAK_PT * m + 1][k], sp[GPAK_PT * m + 2][k],
+                                  sp[GPAK_PT * m + 3][k], sp[GPAK_PT * m + 4][k], b[m][0], b[m][1], b[m][2], b[m][3],
+                                  b[m][4], kp.mode);
         kv += gpak_profile(d2, kp.term[m]);
       }
-      acc = fma(sp[MT * 4][k], kv, acc);
+      acc = fma(sp[MT * GPAK_PT][k], kv, acc);
     }
   }
   if (ok) part[(size_t)blockIdx.y * part_ld + j] = acc;

@@ -55,7 +55,7 @@ static int ensure_predict_bufs(gpak_ctx *ctx, int cap, bool want_var) {
     if (ctx->dPv) hipFree(ctx->dPv);
     if (ctx->dPart) hipFree(ctx->dPart);
     ctx->dXte = ctx->dPv = ctx->dPart = nullptr;
-    if (hipMalloc(&ctx->dXte, sizeof(double) * 3 * (size_t)cap) != hipSuccess ||
+    if (hipMalloc(&ctx->dXte, sizeof(double) * 4 * (size_t)cap) != hipSuccess ||
         hipMalloc(&ctx->dPv, sizeof(double) * 2 * (size_t)cap) != hipSuccess ||
         hipMalloc(&ctx->dPart, sizeof(double) * 64 * (size_t)cap) != hipSuccess) {
       ctx->err = "device allocation failed for prediction buffers";
@@ -167,10 +167,11 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   GPAK_HIP(hipEventRecord(e0, st));
 
   // pooled mean over train u (all) test points: Kernel.cpp:1391-1392 with X1 = Xinp, X2 = Xin
-  double s2[3] = {0, 0, 0};
-  for (int k = 0; k < 3; k++)
+  double s2[4] = {0, 0, 0, 0};
+  for (int k = 0; k < ctx->d; k++)
     for (long i = 0; i < M; i++) s2[k] += Xte[i + (size_t)k * M];
   KernParams kp = ctx->kp;
+  kp.d = ctx->d;
   gpak_pooled_mean(ctx->xsum, N, s2, M, kp.mu);
   gpak_launch_transform(st, ctx->dX, Np, N, kp, ctx->Upred);
 
@@ -181,8 +182,8 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   for (long b0 = 0; b0 < M; b0 += cap) {
     const int mb = (int)std::min<long>(cap, M - b0);
     const int mbp = (mb + PB - 1) / PB * PB;
-    GPAK_HIP(hipMemsetAsync(ctx->dXte, 0, sizeof(double) * 3 * (size_t)cap, st));
-    for (int k = 0; k < 3; k++)
+    GPAK_HIP(hipMemsetAsync(ctx->dXte, 0, sizeof(double) * 4 * (size_t)cap, st));
+    for (int k = 0; k < ctx->d; k++)
       GPAK_HIP(hipMemcpyAsync(ctx->dXte + (size_t)k * cap, Xte + (size_t)k * M + b0, sizeof(double) * mb,
                               hipMemcpyHostToDevice, st));
     gpak_launch_transform(st, ctx->dXte, cap, mb, kp, ctx->Tq);

@@ -173,7 +173,7 @@ class DistGP:
         yp[:self.N] = y
         self.y = engine.from_numpy(yp)
         self.xsum = X.sum(axis=0)
-        self.u = engine.empty(4 * self.cap)
+        self.u = engine.empty(5 * self.cap)   # u0, u1, u2, |u|^2, u3 (include/gpak_dev.h)
         # the rank's block columns side by side in ONE array (nb columns each, leading dimension ld), so
         # that the trailing update of all of them is a single launch (gpak_dev_update_cyclic)
         self.local = engine.empty(max(1, len(self.owned)) * self.nb * self.ld)

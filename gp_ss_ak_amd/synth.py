@@ -49,6 +49,9 @@ def symmetric_standardise(X, y):
     params = np.zeros((X.shape[1] + 1, 2))
     params[0] = (0.5 * (yhi + ylo), 0.5 * (yhi - ylo))
     params[1:4] = (0.5 * (hi + lo), 0.5 * (hi - lo))
+    for j in range(3, X.shape[1]):   # further columns (rock type): their own range, Control.cpp:311-315;
+        cj = X[:, j]                 # lo/hi above are over ALL input columns, as Control.h:51-52 has it
+        params[j + 1] = (0.5 * (cj.max() + cj.min()), 0.5 * (cj.max() - cj.min()))
     Xs = (X - params[1:, 0][None, :]) / params[1:, 1][None, :]
     ys = (y - params[0, 0]) / params[0, 1]
     return np.asfortranarray(Xs), np.ascontiguousarray(ys), params
@@ -59,6 +62,32 @@ def drillholes(N, seed=None):
     X, y = drillholes_raw(N, seed)
     Xs, ys, _ = symmetric_standardise(X, y)
     return Xs, ys
+
+
+def rock_codes(X_raw, seed=0):
+    """A synthetic rock-type code 1..4 per sample: banded along a tilted direction, with 5 % mislogged."""
+    rng = np.random.default_rng(4171 + len(X_raw) + seed)
+    t = X_raw @ np.array([0.35, -0.2, 0.9])
+    band = np.floor(4.0 * (t - t.min()) / (np.ptp(t) + 1e-12)).clip(0, 3)
+    flip = rng.random(len(t)) < 0.05
+    band[flip] = rng.integers(0, 4, flip.sum())
+    return band + 1.0
+
+
+def drillholes4(N, seed=None):
+    """Standardised 4-column training set: x, y, z + rock-type code."""
+    X, y = drillholes_raw(N, seed)
+    X4 = np.column_stack([X, rock_codes(X)])
+    Xs, ys, _ = symmetric_standardise(X4, y)
+    return Xs, ys
+
+
+def test_points4(M, seed=0):
+    """Test locations with a rock-type column drawn from the four standardised codes."""
+    P = test_points(M, seed)
+    rng = np.random.default_rng(77 + M + seed)
+    codes = rng.integers(0, 4, M) * (2.0 / 3.0) - 1.0
+    return np.asfortranarray(np.column_stack([P, codes]))
 
 
 def test_points(M, seed=0):

@@ -36,7 +36,7 @@ typedef struct gpak_ctx gpak_ctx;
 #define GPAK_EINVAL   2   /* bad argument                                                */
 #define GPAK_ESTATE   3   /* call out of order (e.g. no training set yet)                */
 #define GPAK_ENOMEM   4   /* device allocation failed                                    */
-#define GPAK_ENOTIMPL 5   /* feature not built yet (e.g. 4-D inputs)                     */
+#define GPAK_ENOTIMPL 5   /* not built (input columns other than 3 or 4, White gradient) */
 #define GPAK_EHIP    (-1) /* HIP runtime error                                           */
 
 /* precision (fixed at ctx creation).  GPAK_F64: everything in fp64.  GPAK_F32 (BASELINE.json
@@ -65,7 +65,9 @@ const char *gpak_global_error(void);
 
 /* ---- model state ------------------------------------------------------------------------ */
 /* GP_utils ctor / test-time reload: members Xinp (N x d) and yTarg (N x 1)
- * (GP_Utils.cpp:9-46, gp_ss_ak.cpp:384-395).  d must be 3 on the HIP path. */
+ * (GP_Utils.cpp:9-46, gp_ss_ak.cpp:384-395).  d = 3 (x, y, z) or d = 4: a 4th "rock type" column that enters
+ * the ExpAns distance with its own inverse width InversewidthR (Kernel.cpp:1411-1424) and the
+ * Euclidean distance of Exp / RBF children like any other column (Kernel.cpp:1356-1362). */
 int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d);
 
 /* GP_utils::set_GP_Pars (GP_Utils.cpp:130-157): expans[8] in the reference's order

@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-/* u = (x - mu) * sigInv for the N points, SoA: u is 4*cap doubles {u0[cap],u1[cap],u2[cap],|u|^2[cap]}.
+/* u = (x - mu) * sigInv for the N points, SoA: u is 5*cap doubles {u0[cap],u1[cap],u2[cap],|u|^2[cap],u3[cap]}
+ * (u3 = transformed 4th input column of the context-level API; zero here, the distributed path is 3-D).
  * x is SoA with stride xs.  mu[3] is the pooled mean (Kernel.cpp:1391-1392), expans[8] as gpak_set_params. */
 int gpak_dev_transform(void *stream, const double *x, int xs, int n, int cap, const double *expans,
                        const double *mu, double *u);

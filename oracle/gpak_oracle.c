@@ -761,6 +761,17 @@ static void expans_S_matrices(const double *e, double S[9], double Sp[6][9]) {
 void orc_grad_ref(const double *X, int N, const double *y, const double *K, const double *L,
                   const double *alpha, const double *expans, double bias, double sn2, int mode,
                   double *g) {
+  orc_grad_ref_d(X, N, 3, y, K, L, alpha, expans, bias, sn2, mode, g);
+}
+
+/* The same for d = 3 or d = 4 input columns.  With a 4th ("rock type") column: the distance carries it
+ * (A33 = InversewidthR, Kernel.cpp:1411-1424), S(3,3) = 1 but every S_p(3,3) = 0, so g0..g5 see only the
+ * first three columns (:1169-1173), and g7 = -2 * sum(KD2 % Di2_R) / N with Di2_R = 2 (x4_i - x4_j)^2 --
+ * the weight there is KD2 = exp(-sqrt(DD2)), NOT R: RColon still holds KD2 from the Sigma block
+ * (:1239-1253), reproduced as written. */
+void orc_grad_ref_d(const double *X, int N, int d, const double *y, const double *K, const double *L,
+                    const double *alpha, const double *expans, double bias, double sn2, int mode,
+                    double *g) {
   (void)bias;
   size_t NN = (size_t)N * N;
   double Sw = sqrt(1.0 / sn2);
@@ -783,7 +794,7 @@ void orc_grad_ref(const double *X, int N, const double *y, const double *K, cons
   double par[7];
   pack_paramker(expans, par);
   double *DD2 = (double *)malloc(sizeof(double) * NN);
-  orc_mahadist(X, N, X, N, 3, par, mode, DD2);              /* :925 */
+  orc_mahadist(X, N, X, N, d, par, mode, DD2);              /* :925 */
   double var2 = expans[6] * expans[6];
   double S[9], Sp[6][9];
   expans_S_matrices(expans, S, Sp);
@@ -832,6 +843,16 @@ void orc_grad_ref(const double *X, int N, const double *y, const double *K, cons
   }
   g[6] = 2.0 * gsig * expans[6];                            /* :1241-1242 */
   g[7] = 0.0;                                               /* :1256-1257 */
+  if (d == 4) {                                             /* :1246-1255 */
+    const double *x4 = X + (size_t)3 * N;
+    double acc = 0.0;
+    for (int j = 0; j < N; j++)
+      for (int i = 0; i < N; i++) {
+        double Di2 = 2.0 * x4[i] * x4[i] + 2.0 * x4[j] * x4[j] - 4.0 * x4[i] * x4[j];
+        acc += exp(-1.0 * sqrt(DD2[i + (size_t)j * N])) * Di2;
+      }
+    g[7] = -2.0 * acc / N;
+  }
   /* Kern_Bias::getGradients, Kernel.cpp:370-377: sum(QW % eye) */
   double tr = 0.0;
   for (int i = 0; i < N; i++) tr += QW[i + (size_t)i * N];
@@ -858,6 +879,13 @@ void orc_grad_ref(const double *X, int N, const double *y, const double *K, cons
  * g: per child in order (8 / 2 / 3 entries), then bias (if has_bias), then sn2. */
 void orc_grad_hyb(const double *X, int N, const double *y, const double *K, const double *L, const double *alpha,
                   int nterms, const int *kinds, const double *pars, int has_bias, double sn2, int mode, double *g) {
+  orc_grad_hyb_d(X, N, 3, y, K, L, alpha, nterms, kinds, pars, has_bias, sn2, mode, g);
+}
+
+/* d = 3 or 4 input columns (the 4th enters every child's distance; ExpAns' g7 as in orc_grad_ref_d) */
+void orc_grad_hyb_d(const double *X, int N, int d, const double *y, const double *K, const double *L,
+                    const double *alpha, int nterms, const int *kinds, const double *pars, int has_bias, double sn2,
+                    int mode, double *g) {
   size_t NN = (size_t)N * N;
   double Sw = sqrt(1.0 / sn2);
   double *Q = (double *)calloc(NN, sizeof(double));
@@ -876,9 +904,9 @@ void orc_grad_hyb(const double *X, int N, const double *y, const double *K, cons
   double *D2s = (double *)calloc(NN, sizeof(double)), *D = (double *)malloc(sizeof(double) * NN);
   const double *p = pars;
   for (int t = 0; t < nterms; t++) {
-    if (kinds[t] == 0) { double par[7]; pack_paramker(p, par); orc_mahadist(X, N, X, N, 3, par, mode, D); p += 8; }
-    else if (kinds[t] == 1) { orc_eucldist(X, N, X, N, 3, p[0], mode, D); p += 2; }
-    else { orc_eucldist(X, N, X, N, 3, p[0], mode, D); p += 3; }
+    if (kinds[t] == 0) { double par[7]; pack_paramker(p, par); orc_mahadist(X, N, X, N, d, par, mode, D); p += 8; }
+    else if (kinds[t] == 1) { orc_eucldist(X, N, X, N, d, p[0], mode, D); p += 2; }
+    else { orc_eucldist(X, N, X, N, d, p[0], mode, D); p += 3; }
     for (size_t e = 0; e < NN; e++) D2s[e] += D[e];
   }
   int go = 0;
@@ -888,7 +916,7 @@ void orc_grad_hyb(const double *X, int N, const double *y, const double *K, cons
       /* reuse the ExpAns restatement on QW directly */
       double par[7];
       pack_paramker(p, par);
-      orc_mahadist(X, N, X, N, 3, par, mode, D);
+      orc_mahadist(X, N, X, N, d, par, mode, D);
       double var2 = p[6] * p[6], S[9], Sp[6][9];
       expans_S_matrices(p, S, Sp);
       double *R = (double *)malloc(sizeof(double) * NN);
@@ -925,6 +953,16 @@ void orc_grad_hyb(const double *X, int N, const double *y, const double *K, cons
       }
       g[go + 6] = 2.0 * gsig * p[6];
       g[go + 7] = 0.0;
+      if (d == 4) {                                         /* Kernel.cpp:1246-1255, weight KD2 as written */
+        const double *x4 = X + (size_t)3 * N;
+        double acc = 0.0;
+        for (int j = 0; j < N; j++)
+          for (int i = 0; i < N; i++) {
+            double dx = x4[i] - x4[j];
+            acc += exp(-1.0 * sqrt(D[i + (size_t)j * N])) * 2.0 * dx * dx;
+          }
+        g[go + 7] = -2.0 * acc / N;
+      }
       free(R);
       go += 8; p += 8;
     } else if (kinds[t] == 1) {   /* Kern_Exponential::getGradients, Kernel.cpp:644-693 */

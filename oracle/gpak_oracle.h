@@ -114,9 +114,18 @@ void orc_grad_ref(const double *X, int N, const double *y, const double *K,
                   const double *L, const double *alpha, const double *expans,
                   double bias, double sn2, int mode, double *g);
 
+/* the same for d = 3 or 4 input columns (4th = rock type); g[7] is non-zero only for d = 4 */
+void orc_grad_ref_d(const double *X, int N, int d, const double *y, const double *K,
+                    const double *L, const double *alpha, const double *expans,
+                    double bias, double sn2, int mode, double *g);
+
 /* GradLL for an arbitrary composition; see the .c file.  g: children in order (8 / 2 / 3), bias, sn2 */
 void orc_grad_hyb(const double *X, int N, const double *y, const double *K, const double *L, const double *alpha,
                   int nterms, const int *kinds, const double *pars, int has_bias, double sn2, int mode, double *g);
+
+void orc_grad_hyb_d(const double *X, int N, int d, const double *y, const double *K, const double *L,
+                    const double *alpha, int nterms, const int *kinds, const double *pars, int has_bias, double sn2,
+                    int mode, double *g);
 
 #ifdef __cplusplus
 }

@@ -183,8 +183,8 @@ def grad_ref(X, y, K, L, alpha, expans, bias, sn2, mode=DIST_EXPANSION):
     alpha = np.ascontiguousarray(alpha, dtype=np.float64)
     e = np.ascontiguousarray(expans, dtype=np.float64)
     g = np.zeros(10)
-    lib().orc_grad_ref(_p(X), C.c_int(N), _p(y), _p(K), _p(L), _p(alpha), _p(e), C.c_double(bias),
-                       C.c_double(sn2), C.c_int(mode), _p(g))
+    lib().orc_grad_ref_d(_p(X), C.c_int(N), C.c_int(X.shape[1]), _p(y), _p(K), _p(L), _p(alpha), _p(e),
+                         C.c_double(bias), C.c_double(sn2), C.c_int(mode), _p(g))
     return g
 
 
@@ -197,6 +197,6 @@ def grad_hyb(X, y, K, L, alpha, terms, has_bias, sn2, mode=DIST_EXPANSION):
     pars = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64) for _, p in terms]))
     ng = sum({0: 8, 1: 2, 2: 3}[int(k)] for k, _ in terms) + (1 if has_bias else 0) + 1
     g = np.zeros(ng)
-    lib().orc_grad_hyb(_p(X), C.c_int(N), _p(y), _p(K), _p(L), _p(alpha), C.c_int(len(terms)), kinds, _p(pars),
-                       C.c_int(1 if has_bias else 0), C.c_double(sn2), C.c_int(mode), _p(g))
+    lib().orc_grad_hyb_d(_p(X), C.c_int(N), C.c_int(X.shape[1]), _p(y), _p(K), _p(L), _p(alpha), C.c_int(len(terms)),
+                         kinds, _p(pars), C.c_int(1 if has_bias else 0), C.c_double(sn2), C.c_int(mode), _p(g))
     return g

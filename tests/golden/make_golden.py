@@ -22,10 +22,14 @@ E = np.array(synth.DEFAULT_EXPANS)
 BIAS, SN2 = synth.DEFAULT_BIAS, synth.DEFAULT_SN2
 
 
-def one(N):
+def one(N, d=3):
     orc.use_builtin()
-    X, y = synth.drillholes(N)
-    Xte = synth.test_points(16)
+    if d == 3:
+        X, y = synth.drillholes(N)
+        Xte = synth.test_points(16)
+    else:   # x, y, z + rock-type column
+        X, y = synth.drillholes4(N)
+        Xte = synth.test_points4(16)
     out = {"N": N, "X": X, "y": y, "Xte": Xte, "expans": E, "bias": BIAS, "sn2": SN2}
     for name, mode in (("direct", orc.DIST_DIRECT), ("expansion", orc.DIST_EXPANSION)):
         K = orc.gram(X, X, E, BIAS, mode)
@@ -47,10 +51,12 @@ def one(N):
             out[f"{name}_K"] = K
             out[f"{name}_alpha"] = alpha
             out[f"{name}_L"] = L
-    np.savez_compressed(os.path.join(HERE, f"golden_N{N}.npz"), **out)
-    print("wrote golden_N%d.npz  nlz(direct)=%.15g" % (N, out["direct_nlz"]))
+    tag = f"golden_N{N}" + ("" if d == 3 else f"_d{d}")
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print("wrote %s.npz  nlz(direct)=%.15g" % (tag, out["direct_nlz"]))
 
 
 if __name__ == "__main__":
     for N in (8, 64, 512):
         one(N)
+    one(64, d=4)

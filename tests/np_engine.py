@@ -32,7 +32,7 @@ class NumpyEngine:
     def transform(self, x_soa, xs, n, cap, expans, mu, u):
         X = x_soa.numpy().reshape(3, xs)[:, :n].T
         U = (X - np.asarray(mu)[None, :]) @ self._A(expans)
-        un = u.numpy().reshape(4, cap)
+        un = u.numpy().reshape(5, cap)
         un[:] = 0
         un[:3, :n] = U.T
         un[3, :n] = (U * U).sum(1)
@@ -48,7 +48,7 @@ class NumpyEngine:
         return expans[6] ** 2 * np.exp(-np.sqrt(D2)) + bias
 
     def fill_b(self, u, cap, n, Np, J, W, expans, bias, sn2, mode, blk, ld):
-        un = u.numpy().reshape(4, cap)
+        un = u.numpy().reshape(5, cap)
         M = blk.numpy().reshape(W, ld).T  # (ld x W) column-major view
         M[:Np, :] = 0
         nc = max(0, min(W, n - J))
@@ -121,7 +121,7 @@ class NumpyEngine:
         out[0] = float(np.log(np.diag(M[J:J + nc, :nc])).sum()) if nc else 0.0
 
     def kmatvec(self, u, cap, n, i0, i1, w, expans, bias, mode, scratch, out):
-        un = u.numpy().reshape(4, cap)
+        un = u.numpy().reshape(5, cap)
         K = self._kfun(un, slice(i0, i1), slice(0, n), expans, bias, mode)
         out.numpy()[:n] = w.numpy()[i0:i1] @ K
 

@@ -191,6 +191,82 @@ def test_other_kernel_compositions(gp, orc, mode):
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)   # back to the default composition for later tests
 
 
+@pytest.mark.parametrize("mode", [gpak.DIST_DIRECT, gpak.DIST_EXPANSION])
+def test_four_column_inputs(gp, orc, mode):
+    """x, y, z + rock-type column with its own inverse width (expans[7]); Gram, cross-Gram, nlZ,
+    alpha, prediction, the reference-style gradient (g7 != 0 here) and a composition with Exp / RBF children."""
+    N, M = 600, 50
+    X, y = synth.drillholes4(N)
+    Xt = synth.test_points4(M)
+    direct = mode == gpak.DIST_DIRECT
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, mode)
+    K, D2 = gp.gram(want_d2=True)
+    Ko, D2o = orc.gram(X, X, E, BIAS, mode, want_d2=True)
+    assert rel(K, Ko) <= (1e-13 if direct else 2e-7) and np.abs(D2 - D2o).max() <= 1e-12
+    K3 = orc.gram(X[:, :3].copy(order="F"), X[:, :3].copy(order="F"), E, BIAS, mode)
+    assert np.abs(K3 - Ko).max() > 1e-2                  # the rock-type column matters
+    assert rel(gp.compute_k(X, Xt), orc.gram(X, Xt, E, BIAS, mode)) <= (1e-13 if direct else 2e-7)
+    info, alpha_o, Lo = orc.nlz_refseq(Ko, y, SN2)
+    assert abs(gp.logLikelihood() - info.nlz) <= (1e-9 if direct else 1e-6) * abs(info.nlz)
+    assert rel(gp.solve_alpha(), alpha_o) <= (1e-8 if direct else 1e-5)
+    mean, var = gp.posteriorMeanVar(Xt, compat=3)
+    mo, vo = orc.predict(X, Xt, E, BIAS, SN2, alpha_o, Lo, mode, compat=3)
+    assert rel(mean, mo) <= (1e-8 if direct else 1e-5) and rel(var, vo) <= (1e-8 if direct else 1e-5)
+    g = gp.GradLL()
+    go = orc.grad_ref(X, y, Ko, Lo, alpha_o, E, BIAS, SN2, mode)
+    assert go[7] != 0.0
+    assert np.abs(g - go).max() <= (1e-8 if direct else 1e-5) * np.abs(go).max()
+    assert abs(g[7] - go[7]) <= (1e-10 if direct else 1e-6) * abs(go[7])
+    with pytest.raises(gpak.GpakError) as ei:
+        gp.posteriorMeanVar(Xt[:, :3].copy(order="F"))
+    assert ei.value.status == gpak.EINVAL                # column count must match the training set
+    terms = [(gpak.KERN_EXPANS, E), (gpak.KERN_RBF, [0.5, 0.9, 0.5]), (gpak.KERN_EXP, [0.6, 0.7])]
+    gp.set_kernel(terms, BIAS, 0.0, SN2, mode)
+    Kh = orc.gram_hyb(X, X, terms, BIAS, 0.0, mode)
+    assert rel(gp.gram(), Kh) <= (1e-13 if direct else 2e-7)
+    ih, ah, Lh = orc.nlz_lean(Kh, y, SN2)
+    assert abs(gp.logLikelihood() - ih.nlz) <= (1e-9 if direct else 1e-6) * abs(ih.nlz)
+    gh = gp.GradLL_hyb(8 + 3 + 2 + 2)
+    gho = orc.grad_hyb(X, y, Kh, Lh, ah, terms, True, SN2, mode)
+    assert np.abs(gh - gho).max() <= (1e-8 if direct else 1e-5) * np.abs(gho).max()
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+
+
+def test_hip_path_matches_committed_golden_vectors(gp):
+    """The committed fixtures (tests/golden/*.npz, frozen oracle output: parity unpinned by the reference) against
+    the HIP path, without building or calling the oracle on this box."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_N*.npz")))
+    assert len(files) == 4
+    for f in files:
+        z = np.load(f)
+        X, y, Xte = np.asfortranarray(z["X"]), z["y"], np.asfortranarray(z["Xte"])
+        gp.set_train(X, y)
+        for name, mode in (("direct", gpak.DIST_DIRECT), ("expansion", gpak.DIST_EXPANSION)):
+            direct = mode == gpak.DIST_DIRECT
+            gp.set_params(z["expans"], float(z["bias"]), float(z["sn2"]), mode)
+            K = gp.gram()
+            ij = z[f"{name}_sample_ij"]
+            assert np.abs(K[ij[0], ij[1]] - z[f"{name}_K_samples"]).max() <= (1e-13 if direct else 2e-7)
+            nlz = gp.logLikelihood()
+            assert abs(nlz - float(z[f"{name}_nlz"])) <= (1e-9 if direct else 1e-6) * abs(nlz)
+            q, s, l = gp.nlz_terms()
+            assert abs(l - float(z[f"{name}_logdet"])) <= (1e-10 if direct else 1e-6) * abs(l)
+            mean, var = gp.posteriorMeanVar(Xte)
+            assert rel(mean, z[f"{name}_mean"]) <= (1e-8 if direct else 1e-5)
+            assert rel(var, z[f"{name}_var"]) <= (1e-8 if direct else 1e-5)
+            mean, var = gp.posteriorMeanVar(Xte, compat=3)
+            assert rel(var, z[f"{name}_var_compat"]) <= (1e-8 if direct else 1e-5)
+            g = gp.GradLL()
+            go = z[f"{name}_grad"]
+            assert np.abs(g - go).max() <= (1e-8 if direct else 1e-5) * np.abs(go).max()
+            if f"{name}_alpha" in z:
+                assert rel(gp.solve_alpha(), z[f"{name}_alpha"]) <= (1e-8 if direct else 1e-5)
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+
+
 def test_full_size_properties_n32768(gp):
     """BASELINE.json's full size (N=32768, fp64): no CPU oracle finishes here in seconds, so the
     step is checked through identities that hold at any size:

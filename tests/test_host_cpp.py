@@ -171,3 +171,60 @@ def test_cli_train_then_test_config1(tmp_path):
     pred = np.loadtxt(model + "_predict.txt", comments="#")
     assert pred.shape == (128, 7) and np.all(np.diff(pred[:, 1]) >= 0)          # sorted by ascending y
     assert os.path.exists(model + "_gnu.plt")
+
+
+@pytest.mark.gpu
+def test_class_surface_four_column_inputs(orc, tmp_path):
+    """SURVEY Q7 through the C++ classes: x, y, z + rock type, InversewidthR_ExpAns in play, g[7] != 0."""
+    build()
+    N, M = 500, 10
+    X, y = synth.drillholes4(N)
+    Xt = synth.test_points4(M)
+    write_csv(tmp_path / "tr.csv", X, y)
+    write_csv(tmp_path / "te.csv", Xt, np.zeros(M))
+    out = subprocess.check_output([os.path.join(HOST, "host_selftest"), str(tmp_path / "tr.csv"),
+                                   str(tmp_path / "te.csv")]).decode()
+    r = json.loads(out[out.index("{"):])
+    assert r["npars"] == 10 and r["param_names"][7] == "InversewidthR_ExpAns"
+    K = orc.gram(X, X, E, 0.2, orc.DIST_DIRECT)
+    info, alpha, L = orc.nlz_refseq(K, y, 0.016)
+    assert abs(r["K_sum"] - K.sum()) <= 1e-12 * abs(K.sum())
+    assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+    g = orc.grad_ref(X, y, K, L, alpha, E, 0.2, 0.016, orc.DIST_DIRECT)
+    assert g[7] != 0.0 and abs(r["grad"][7] - g[7]) <= 1e-9 * abs(g[7])
+    assert np.abs(np.array(r["grad"]) - g).max() <= 1e-8 * np.abs(g).max()
+    mean, var = orc.predict(X, Xt, E, 0.2, 0.016, alpha, L, orc.DIST_DIRECT,
+                            orc.COMPAT_VARCLAMP | orc.COMPAT_SN2SKIP)
+    assert np.abs(np.array(r["mean"]) - mean).max() <= 1e-8 * np.abs(mean).max()
+    assert np.abs(np.array(r["var"]) - var).max() <= 1e-8 * np.abs(var).max()
+
+
+@pytest.mark.gpu
+def test_cli_train_then_test_four_columns(tmp_path):
+    """train / test verbs on files with a rock-type column (inputDim=4 in the model file)."""
+    build()
+    Xr, yr = synth.drillholes_raw(384)
+    Xr = np.column_stack([Xr, synth.rock_codes(Xr)])
+    yr = yr * (1.0 + 0.15 * Xr[:, 3])                      # the grade depends on the rock type
+    perm = np.random.default_rng(7).permutation(384)
+    Xr, yr = Xr[perm], yr[perm]
+    write_csv(tmp_path / "train.txt", Xr[:320], yr[:320], sep="\t")
+    write_csv(tmp_path / "test.txt", Xr[320:], yr[320:], sep="\t")
+    exe = os.path.join(HOST, "gp_ss_ak")
+    model = str(tmp_path / "model4")
+    env = dict(os.environ, GPAK_MAX_ITERS="10")
+    out = subprocess.check_output([exe, "-v", "1", "-np", "train", "-k", "ExpAns", "-kn", "1", "-o", "LBFGS",
+                                   str(tmp_path / "train.txt"), model], env=env, cwd=tmp_path).decode()
+    its = [float(line.split("-logL:")[1]) for line in out.splitlines() if line.startswith("Iteration:")]
+    assert len(its) >= 1 and all(b <= a + 1e-9 for a, b in zip(its, its[1:]))
+    txt = open(model).read().splitlines()
+    assert "inputDim=4" in txt
+    stats = np.loadtxt(model + "_Statistics.txt", delimiter=",")
+    assert stats.shape == (5, 6)
+    assert stats[4, 0] == 2.5 and stats[4, 1] == 1.5           # rock codes 1..4: own centre / half-range
+    assert stats[1, 0] == stats[2, 0] == stats[3, 0]           # x, y, z share one (Control.cpp:304-310)
+    out2 = subprocess.check_output([exe, "-v", "1", "-np", "test", str(tmp_path / "test.txt"), model,
+                                    str(tmp_path / "train.txt")], cwd=tmp_path).decode()
+    mse_test = float(out2.split("Mean Square Error of testing:")[1].split()[0])
+    var_test = float(out2.split("Var MSE Test:")[1].split()[0])
+    assert mse_test < var_test

@@ -30,6 +30,8 @@ def np_gram(X1, X2, e, bias):
     """Independent NumPy statement of SURVEY.md section 0 (direct distance)."""
     R = np_rot(e[0], e[2], e[4])
     A = R @ np.diag([e[1], e[3], e[5]]) @ R.T
+    if X1.shape[1] == 4:                       # rock-type column: A33 = InversewidthR (Kernel.cpp:1411-1424)
+        A = np.block([[A, np.zeros((3, 1))], [np.zeros((1, 3)), np.array([[e[7]]])]])
     U, V = X1 @ A, X2 @ A
     D2 = ((U[:, None, :] - V[None, :, :]) ** 2).sum(-1)
     return e[6] ** 2 * np.exp(-np.sqrt(D2)) + bias, D2
@@ -230,11 +232,16 @@ def np_grad_as_written(X, y, e, bias, sn2):
         SL = np.outer(R[:, a], R[:, a])
         for slot, Sp in ((2 * a, Sa), (2 * a + 1, SL)):
             Mp = S * Sp
-            av = (2 * X * X) @ Mp
-            Di2 = av.sum(1)[:, None] + av.sum(1)[None, :] - 4 * X @ Mp @ X.T
+            X3 = X[:, :3]                                # S_p(3,3) = 0: the 4th column drops out (:1169-1173)
+            av = (2 * X3 * X3) @ Mp
+            Di2 = av.sum(1)[:, None] + av.sum(1)[None, :] - 4 * X3 @ Mp @ X3.T
             g[slot] = (Rm * Di2).sum()
     g[6] = 2 * (np.exp(-SD) * QW).sum() * e[6]
     g[7] = 0.0
+    if X.shape[1] == 4:                                  # Kernel.cpp:1246-1255, weight = KD2 as written
+        x4 = X[:, 3]
+        Di2 = 2 * x4[:, None] ** 2 + 2 * x4[None, :] ** 2 - 4 * np.outer(x4, x4)
+        g[7] = -2 * (np.exp(-SD) * Di2).sum() / N
     g[8] = np.trace(QW)
     f = K @ alpha
     g[9] = -(2 / sn2) * dW.sum() - (((y - f) ** 2) / sn2 - 1).sum()
@@ -254,9 +261,38 @@ def test_reference_style_gradient_against_numpy(orc):
     assert np.abs(g[[1, 3, 5, 6, 8, 9]] - gn[[1, 3, 5, 6, 8, 9]]).max() <= 1e-9 * scale
 
 
+def test_four_column_inputs_gram_gradient_prediction(orc):
+    """a 4th (rock-type) input column with its own inverse width."""
+    N = 70
+    X, y = synth.drillholes4(N)
+    assert X.shape == (N, 4) and abs(X[:, 3]).max() == 1.0 and len(np.unique(X[:, 3])) == 4
+    Kn, D2n = np_gram(X, X, E, BIAS)
+    for mode, tol in ((orc.DIST_DIRECT, 1e-13), (orc.DIST_EXPANSION, 1e-6)):
+        K, D2 = orc.gram(X, X, E, BIAS, mode, want_d2=True)
+        assert np.abs(K - Kn).max() <= tol
+    # the 4th column matters: same coordinates, different rock type => smaller covariance
+    X2 = X.copy()
+    X2[:, 3] = -X2[:, 3]
+    assert np.abs(orc.gram(X, X2, E, BIAS, orc.DIST_DIRECT) - Kn).max() > 1e-3
+    K = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+    info, alpha, L = orc.nlz_lean(K, y, SN2)
+    g = orc.grad_ref(X, y, K, L, alpha, E, BIAS, SN2, orc.DIST_DIRECT)
+    gn = np_grad_as_written(X, y, E, BIAS, SN2)
+    scale = np.abs(gn).max()
+    assert g[7] != 0.0 and abs(g[7] - gn[7]) <= 1e-10 * abs(gn[7])
+    assert np.abs(g - gn).max() <= 2e-6 * scale
+    Xt = synth.test_points4(25)
+    mean, var = orc.predict(X, Xt, E, BIAS, SN2, alpha, L, orc.DIST_DIRECT)
+    kX, _ = np_gram(X, Xt, E, BIAS)
+    assert np.abs(mean - kX.T @ alpha).max() <= 1e-10
+    C = K + SN2 * np.eye(N)
+    vn = (E[6] ** 2 + BIAS) - np.einsum("ij,ij->j", kX, np.linalg.solve(C, kX)) + SN2
+    assert np.abs(var - vn).max() <= 1e-9
+
+
 def test_golden_vectors_still_match_the_oracle(orc):
     files = sorted(glob.glob(os.path.join(GOLD, "golden_N*.npz")))
-    assert len(files) == 3
+    assert len(files) == 4   # N = 8, 64, 512 (3-D) and N = 64 with a rock-type column
     orc.use_builtin()
     for f in files:
         z = np.load(f)  # allow_pickle=False by default
