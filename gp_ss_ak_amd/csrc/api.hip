@@ -348,7 +348,7 @@ static int ensure_alpha(gpak_ctx *ctx) {
     gpak_launch_trsv_fwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
   }
   ctx->z_ok = false;  // the back substitution consumes w1
-  gpak_launch_trsv_bwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha);
+  gpak_launch_trsv_bwd2(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha, ctx->dWork + 2 * (size_t)ctx->Np);
   GPAK_HIP(hipEventRecord(ctx->ev[4], st));
   GPAK_HIP(hipEventSynchronize(ctx->ev[4]));
   float ms = 0;

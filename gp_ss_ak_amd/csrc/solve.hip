@@ -109,6 +109,119 @@ void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Two-level back substitution  out = L^-T z  (the second solve of solve_chol, GP_Utils.cpp:844):
+// per 512-column block column J, from the last to the first,
+//   1. gpak_coldot_split_f64: s[c] = sum_{i >= J+W} L[i, c] out[i] for its W columns -- full columns,
+//      streamed once (Np^2/2 * 8 B over the whole solve), rows split over up to 8 workgroups per
+//      column group so that ~512 workgroups are in flight;
+//   2. gpak_trsv_bwd_diag_f64: ONE workgroup solves the W x W diagonal block: v = z_J - s, then for
+//      each 128-column sub-block from the last: out_k = inv(L_kk)^T v_k, v_c -= L[k rows, c]^T out_k for
+//      the earlier columns c of the block.
+// 2 launches per 512 columns instead of 4 (one per 128 columns) that each re-read inv and
+// hand off through global memory: 128 launches for N=32768 instead of 256.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpak_coldot_split_f64(int Np, int i0, int J, int W, int rows_per_split,
+                                                              const double *__restrict__ L, long ld,
+                                                              const double *__restrict__ x, double *__restrict__ part,
+                                                              int part_ld) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = J + blockIdx.x * 4 + w;
+  if (c >= J + W) return;
+  const int rb = i0 + blockIdx.y * rows_per_split;
+  const int re = min(Np, rb + rows_per_split);
+  const double *Lc = L + (size_t)c * ld;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  int i = rb + 2 * lane;
+  for (; i + 128 < re; i += 256) {   // two independent 1-KiB pieces per trip
+    const double2 l0 = *reinterpret_cast<const double2 *>(Lc + i), v0 = *reinterpret_cast<const double2 *>(x + i);
+    const double2 l1 = *reinterpret_cast<const double2 *>(Lc + i + 128), v1 = *reinterpret_cast<const double2 *>(x + i + 128);
+    a0 = fma(l0.x, v0.x, a0); a1 = fma(l0.y, v0.y, a1);
+    b0 = fma(l1.x, v1.x, b0); b1 = fma(l1.y, v1.y, b1);
+  }
+  for (; i < re; i += 128) {
+    const double2 l0 = *reinterpret_cast<const double2 *>(Lc + i), v0 = *reinterpret_cast<const double2 *>(x + i);
+    a0 = fma(l0.x, v0.x, a0); a1 = fma(l0.y, v0.y, a1);
+  }
+  double a = (a0 + a1) + (b0 + b1);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  if (lane == 0) part[(size_t)blockIdx.y * part_ld + (c - J)] = a;
+}
+
+#define BD_MAXW 512
+__global__ __launch_bounds__(1024) void gpak_trsv_bwd_diag_f64(int J, int W, const double *__restrict__ L, long ld,
+                                                                const double *__restrict__ inv,
+                                                                const double *__restrict__ z,
+                                                                const double *__restrict__ part, int nsplit,
+                                                                int part_ld, double *__restrict__ out) {
+  __shared__ double v[BD_MAXW], o[SB], ps[8][SB];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < W) {
+    double s = 0.0;
+    for (int r = 0; r < nsplit; r++) s += part[(size_t)r * part_ld + t];  // fixed order
+    v[t] = z[J + t] - s;
+  }
+  __syncthreads();
+  for (int k = W / SB - 1; k >= 0; k--) {
+    const int j0 = J + k * SB;
+    // out_k = inv(L_kk)^T v_k : 128 rows x 8 slices of 16 k'
+    {
+      const double *ibT = inv + (size_t)(j0 / SB) * 2 * SB * SB + SB * SB;  // inv(L_kk)^T, column-major
+      const int i = t & (SB - 1), sl = t >> 7;
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; q++) s = fma(ibT[i + (size_t)(16 * sl + q) * SB], v[k * SB + 16 * sl + q], s);
+      ps[sl][i] = s;
+    }
+    __syncthreads();
+    if (t < SB) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) s += ps[q][t];
+      o[t] = s;
+      out[j0 + t] = s;
+    }
+    __syncthreads();
+    // v_c -= sum_r L[j0 + r, J + c] o[r] for the earlier columns of the block: a wave per column
+    const double o0 = o[2 * lane], o1 = o[2 * lane + 1];
+    // k * 128 columns over 16 waves = 8 k per wave: all of a wave's loads in flight together
+    for (int cb = 0; cb < k; cb++) {
+      double2 l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        l[u] = *reinterpret_cast<const double2 *>(L + j0 + 2 * lane + (size_t)(J + cb * SB + w + 16 * u) * ld);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        double s = l[u].x * o0 + l[u].y * o1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) v[cb * SB + w + 16 * u] -= s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// scratch: 8 * 512 doubles
+void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
+                           double *out, double *scratch) {
+  const int NB = BD_MAXW;
+  const int nJ = (Np + NB - 1) / NB;
+  for (int b = nJ - 1; b >= 0; b--) {
+    const int J = b * NB, W = min(NB, Np - J), rows = Np - (J + W);
+    int R = 0, per = 0;
+    if (rows > 0) {
+      R = (rows + 4095) / 4096;
+      if (R > 8) R = 8;
+      per = ((rows + R - 1) / R + 127) / 128 * 128;
+      hipLaunchKernelGGL(gpak_coldot_split_f64, dim3(W / 4, R), dim3(256), 0, st, Np, J + W, J, W, per, L, ld, out,
+                         scratch, NB);
+    }
+    hipLaunchKernelGGL(gpak_trsv_bwd_diag_f64, dim3(1), dim3(1024), 0, st, J, W, L, ld, inv, z, scratch, R, NB, out);
+  }
+}
+
 // ---- block-column pieces for a factor that is distributed by block columns ---------------
 // forward: the four (W/128) steps of block column [J, J+W); x[r] is updated for ALL r below
 void gpak_launch_trsv_fwd_block(hipStream_t st, int Np, int J, int W, const double *L, long ld,
