@@ -588,7 +588,9 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
       if (first < mt) tiles += mt - first;
     }
   }
-  if (!use_lds && tiles <= small_max) {
+  // (the bulk trailing update keeps its own kernel whatever its size: it is never on the panel chain, and
+  //  one kernel name per role keeps the rocprofv3 statistics and bench.py's event timing comparable)
+  if (!use_lds && !trailing && tiles <= small_max) {
     hipLaunchKernelGGL(gpak_gemm_nt_f64_rs32, dim3((unsigned)(2 * mt * nt)), dim3(512), 0, st, K, alpha, A, lda, B, ldb,
                        beta, C, ldc, row_block0, col_block0, lower_skip ? 1 : 0, 2 * mt, nt, k0_by_row ? 1 : 0);
     return;
