@@ -123,9 +123,6 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   for (int i = 0; i < 8; i++) hipEventCreate(&ctx->ev[i]);
   hipMalloc(&ctx->dRed, sizeof(double) * 64);
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
-  hipMalloc(&ctx->dQueue, sizeof(int) * 8 * 256);
-  if (const char *pe = getenv("GPAK_PERSISTENT")) ctx->persistent = atoi(pe) != 0;
-  if (const char *pe = getenv("GPAK_PERSIST_TILES")) ctx->persist_tiles = atoi(pe) > 0 ? atoi(pe) : 8;
   if (const char *pe = getenv("GPAK_FWD_IN_FACTOR")) ctx->fwd_in_factor = atoi(pe) != 0;
   const char *nb = getenv("GPAK_NB_OUTER");
   if (nb) ctx->nb_outer = atoi(nb);
@@ -141,7 +138,6 @@ void gpak_destroy(gpak_ctx *ctx) {
   gpak_predict_release(ctx);
   if (ctx->dRed) hipFree(ctx->dRed);
   if (ctx->dInfo) hipFree(ctx->dInfo);
-  if (ctx->dQueue) hipFree(ctx->dQueue);
   for (int i = 0; i < 8; i++) hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   for (auto e : ctx->ev_sync) hipEventDestroy(e);

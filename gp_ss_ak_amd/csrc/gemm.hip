@@ -428,143 +428,6 @@ void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double
                      rt0, 0, 0, mt, nt, 0, P, rank, tpb, lt0);
 }
 
-// ---------------------------------------------------------------------------------------
-// Persistent variant of the bulk trailing update  C -= A A^T  (lower tiles of an mt x mt tile
-// grid, A = the factored panel rows that face C).  512 workgroups (2 per CU) stay resident and
-// pull tiles from eight work queues, one per XCD label (blockIdx & 7): queue x hands out the
-// slots of super-tiles x, x+8, x+16, ... in order, so the workgroups of one XCD still walk one
-// 8x8 super-tile together; an exhausted queue's workgroups steal from the next one.  There is no
-// workgroup turn-over between tiles, no empty workgroups for the slots above the diagonal, and
-// the first k-stage of the NEXT tile is already streaming into the idle LDS buffer while the
-// current tile runs its last stage and its read-modify-write epilogue.
-// queue: 8 ints, zeroed on the stream before the launch.  Every workgroup leaves the loop when
-// all queues are exhausted (a bounded number of atomic adds), so the grid always drains.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gpak_syrk_trailing_f64(int K, const double *A, long lda, double *C,
-                                                                  long ldc, int mt, int *queue, int max_tiles) {
-  __shared__ double lds[2][2][KB][LDS_LD];
-  int *sh_next = reinterpret_cast<int *>(&lds[0][0][0][128]);  // row padding: never written by the LDS-DMA
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wr = w & 1, wc = w >> 1;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int SR = (mt + 7) >> 3;
-  const int nsuper = SR * (SR + 1) / 2;
-  const int home = blockIdx.x & 7;
-  int qsel = 0;
-  typedef const __attribute__((address_space(1))) void *gptr_t;
-  typedef __attribute__((address_space(3))) void *lptr_t;
-
-  // thread 0 only: next valid tile as (ti << 16 | tj), or -1 when every queue is exhausted
-  auto fetch = [&]() -> int {
-    while (qsel < 8) {
-      const int x = (home + qsel) & 7;
-      const int id = atomicAdd(&queue[x], 1);
-      const int ssel = (id >> 6) * 8 + x;
-      if (ssel >= nsuper) { qsel++; continue; }
-      const int slot = id & 63;
-      int sj = 0, rem = ssel;
-      while (rem >= SR - sj) { rem -= SR - sj; sj++; }
-      const int ti = (sj + rem) * 8 + (slot & 7), tj = sj * 8 + (slot >> 3);
-      if (ti >= mt || tj >= mt || ti < tj) continue;
-      return (ti << 16) | tj;
-    }
-    return -1;
-  };
-
-#define GPAK_PSTAGE(buf_, kbase_, ag_, bg_)                                                          \
-  _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                    \
-    const size_t k_ = (size_t)(kbase_) + w + 4 * s;                                                  \
-    __builtin_amdgcn_global_load_lds((gptr_t)((ag_) + k_ * lda), (lptr_t)&lds[buf_][0][w + 4 * s][0], \
-                                     16, 0, 0);                                                      \
-    __builtin_amdgcn_global_load_lds((gptr_t)((bg_) + k_ * lda), (lptr_t)&lds[buf_][1][w + 4 * s][0], \
-                                     16, 0, 0);                                                      \
-  }
-#define GPAK_PCOMPUTE(buf_)                                                                          \
-  _Pragma("unroll") for (int kk = 0; kk < KB / 4; kk++) {                                            \
-    double a[4], b[4];                                                                               \
-    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                 \
-        a[mi] = lds[buf_][0][kk * 4 + l4][wr * 64 + mi * 16 + l15];                                  \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                                 \
-        b[ni] = lds[buf_][1][kk * 4 + l4][wc * 64 + ni * 16 + l15];                                  \
-    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                 \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                             \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0);  \
-  }
-
-  if (t == 0) *sh_next = fetch();
-  __syncthreads();
-  int cur = *sh_next;
-  if (cur < 0) return;
-  const int nstage = K / KB;
-  int bufoff = 0, done = 0;
-  {
-    const double *Ag = A + (size_t)(cur >> 16) * TM + 2 * lane;
-    const double *Bg = A + (size_t)(cur & 0xffff) * TN + 2 * lane;
-    GPAK_PSTAGE(0, 0, Ag, Bg)
-  }
-  while (true) {
-    const int ti = cur >> 16, tj = cur & 0xffff;
-    const double *Ag = A + (size_t)ti * TM + 2 * lane;
-    const double *Bg = A + (size_t)tj * TN + 2 * lane;
-    d4 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-    __syncthreads();  // vmcnt(0) + barrier: this tile's first stage has landed
-    for (int st = 0; st + 1 < nstage; st++) {
-      const int buf = (st + bufoff) & 1;
-      // a workgroup retires after max_tiles tiles so that CU slots keep turning over for the
-      // look-ahead panel's kernels (a grid that never exits starves them)
-      if (st + 2 == nstage && t == 0) *sh_next = (done + 1 < max_tiles) ? fetch() : -1;  // published by this stage's barrier
-      GPAK_PSTAGE(buf ^ 1, (size_t)(st + 1) * KB, Ag, Bg)
-      GPAK_PCOMPUTE(buf)
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-    }
-    const int lbuf = (nstage - 1 + bufoff) & 1;
-    const int nxt = *sh_next;
-    if (nxt >= 0) {
-      // the next tile's first stage streams into the idle buffer under this tile's last stage
-      const double *An = A + (size_t)(nxt >> 16) * TM + 2 * lane;
-      const double *Bn = A + (size_t)(nxt & 0xffff) * TN + 2 * lane;
-      GPAK_PSTAGE(lbuf ^ 1, 0, An, Bn)
-    }
-    GPAK_PCOMPUTE(lbuf)
-    __builtin_amdgcn_sched_barrier(0);
-    double *Cg = C + (size_t)ti * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + l4) * ldc;
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-      double c[4][4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) c[ni][r] = Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc];
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = c[ni][r] - acc[mi][ni][r];
-    }
-    if (nxt < 0) break;
-    cur = nxt;
-    bufoff = lbuf ^ 1;
-    done++;
-  }
-#undef GPAK_PSTAGE
-#undef GPAK_PCOMPUTE
-}
-
-// C (mt x mt lower tiles) -= A A^T with K columns; queue = 8 device ints owned by the caller
-void gpak_launch_syrk_trailing(hipStream_t st, int mt, int K, const double *A, long lda, double *C, long ldc,
-                               int *queue, int max_tiles) {
-  hipMemsetAsync(queue, 0, 8 * sizeof(int), st);
-  const long tiles = (long)mt * (mt + 1) / 2;
-  long wgs = (tiles + max_tiles - 1) / max_tiles + 64;   // spare workgroups exit at once when the queues are empty
-  wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(gpak_syrk_trailing_f64, dim3((unsigned)wgs), dim3(256), 0, st, K, A, lda, C, ldc, mt, queue,
-                     max_tiles);
-}
-
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
                          int col_block0, bool lower_skip, bool trailing, bool k0_by_row) {

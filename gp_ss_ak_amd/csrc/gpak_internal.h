@@ -80,10 +80,6 @@ struct gpak_ctx {
   double *dWork = nullptr;   // 4*Np scratch vectors
   double *dRed = nullptr;    // small reduction scratch
   int *dInfo = nullptr;      // first failing column (1-based) or 0
-  int *dQueue = nullptr;     // ring of 8-int tile queues for the persistent trailing update
-  int queue_next = 0;
-  bool persistent = false;   // multi-tile trailing-update workgroups (gpak_syrk_trailing_f64)
-  int persist_tiles = 8;     // tiles a workgroup processes before it retires
   enum { M_NONE, M_B, M_L } mstate = M_NONE;
   bool alpha_ok = false, nlz_ok = false;
   int failed_col = 0;
@@ -154,15 +150,13 @@ int gpak_ensure_U(gpak_ctx *ctx);
 // ---- gemm.hip ---------------------------------------------------------------------------
 // C[mt x nt tiles of 128] = beta*C + alpha * A (m x K) * B (n x K)^T, all column-major.
 // lower_skip: skip tile (ti,tj) when row_block0+ti < col_block0+tj.
-// trailing=true selects the instantiation named gpak_syrk_trailing_f64 (profiling only).
+// trailing=true selects the instantiation gpak_gemm_nt_f64_rs<4, 2, true> (its own line in profiles).
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
                          int col_block0, bool lower_skip, bool trailing, bool k0_by_row = false);
 
 void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double *Pv, long ldp, double *Clocal,
                              long ldc, int rt0, int P, int rank, int tpb, int lt0);
-void gpak_launch_syrk_trailing(hipStream_t st, int mt, int K, const double *A, long lda, double *C, long ldc,
-                               int *queue, int max_tiles);
 
 // ---- gemm_f32.hip (fp32 prediction path) ---------------------------------------------------
 void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha, const float *A, long lda,

@@ -312,11 +312,6 @@ static void update_cols(gpak_ctx *ctx, hipStream_t st, int J, int W, int c0, int
   const int mt = (ctx->Np - c0) / PB, nt = (c1 - c0) / PB;
   if (mt <= 0 || nt <= 0) return;
   const double *P = M + c0 + (size_t)J * ld;
-  if (trailing && ctx->persistent && mt == nt && mt >= 46 && W >= 32) {  // >= ~1000 lower tiles
-    int *q = ctx->dQueue + 8 * (ctx->queue_next++ & 255);
-    gpak_launch_syrk_trailing(st, mt, W, P, ld, M + c0 + (size_t)c0 * ld, ld, q, ctx->persist_tiles);
-    return;
-  }
   gpak_launch_gemm_nt(st, mt, nt, W, -1.0, P, ld, P, ld, 1.0, M + c0 + (size_t)c0 * ld, ld, 0, 0, true,
                       trailing);
 }
