@@ -233,6 +233,53 @@ def test_four_column_inputs(gp, orc, mode):
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
 
 
+def test_options_and_two_live_contexts(orc):
+    """gpak_set_option: every schedule variant gives the same numbers (look-ahead off = the classical order on
+    one stream; other outer block sizes); value memoisation skips the rebuild only for bit-identical parameters;
+    two contexts do not share state."""
+    N = 1500
+    X, y = synth.drillholes(N)
+    Ko = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+    info, alpha_o, _ = orc.nlz_refseq(Ko, y, SN2)
+    a, b = gpak.Gpak(0), gpak.Gpak(0)
+    try:
+        a.set_train(X, y)
+        b.set_train(X[:700].copy(order="F"), y[:700])
+        a.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        b.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        ref = a.logLikelihood()
+        assert abs(ref - info.nlz) <= 1e-9 * abs(info.nlz)
+        ib, _, _ = orc.nlz_refseq(np.ascontiguousarray(Ko[:700, :700]), y[:700], SN2)
+        assert abs(b.logLikelihood() - ib.nlz) <= 1e-9 * abs(ib.nlz)       # b is untouched by a's work
+        for opt, val in ((gpak.OPT_LOOKAHEAD, 0), (gpak.OPT_NB_OUTER, 128), (gpak.OPT_NB_OUTER, 256),
+                         (gpak.OPT_NB_OUTER, 1024)):
+            a.set_option(opt, val)
+            a.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)                    # invalidates like the reference
+            v = a.logLikelihood()
+            assert abs(v - ref) <= 1e-11 * abs(ref), (opt, val)
+            assert rel(a.solve_alpha(), alpha_o) <= 1e-8
+        a.set_option(gpak.OPT_LOOKAHEAD, 1)
+        a.set_option(gpak.OPT_NB_OUTER, 512)
+        with pytest.raises(gpak.GpakError):
+            a.set_option(gpak.OPT_NB_OUTER, 100)                            # not a multiple of 128
+        a.set_option(gpak.OPT_MEMOISE, 1)
+        a.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        a.logLikelihood()
+        t0 = a.timing()["factor_ms"]
+        a.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)                        # identical values: nothing is rebuilt
+        assert a.logLikelihood() == ref or abs(a.logLikelihood() - ref) <= 1e-11 * abs(ref)
+        assert a.timing()["factor_ms"] == t0
+        e2 = E.copy()
+        e2[1] *= 1.01
+        a.set_params(e2, BIAS, SN2, gpak.DIST_DIRECT)                       # a new value: rebuilt
+        K2 = orc.gram(X, X, e2, BIAS, orc.DIST_DIRECT)
+        i2, _, _ = orc.nlz_lean(K2, y, SN2)
+        assert abs(a.logLikelihood() - i2.nlz) <= 1e-9 * abs(i2.nlz)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_hip_path_matches_committed_golden_vectors(gp):
     """The committed fixtures (tests/golden/*.npz, frozen oracle output: parity unpinned by the reference) against
     the HIP path, without building or calling the oracle on this box."""
