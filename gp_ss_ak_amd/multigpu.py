@@ -465,8 +465,16 @@ def bench(args):
                          f"got WORLD_SIZE={world}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # GPAK_DIST_BACKEND / GPAK_DIST_DEVICE exist for the tests: they rehearse this exact entry point with
+    # several ranks on the ONE GPU of a test box (gloo stages the collectives; RCCL refuses two ranks per GPU)
+    backend = os.environ.get("GPAK_DIST_BACKEND", "nccl")
+    if "GPAK_DIST_DEVICE" in os.environ:
+        local = int(os.environ["GPAK_DIST_DEVICE"])
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     eng = HipEngine(local)
     N = args.n
     X, y = synth.drillholes(N)

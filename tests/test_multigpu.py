@@ -121,3 +121,25 @@ def test_bench_distributed_entry_point_over_rccl():
     assert single.returncode == 0, single.stderr.decode()[-2000:]
     s = json.loads([l for l in single.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_distributed_entry_point_with_several_ranks(world):
+    """bench.py --gpus N as the driver launches it, N ranks rehearsed on this box's one GPU over gloo
+    (sub-panel pipeline on, RCCL replaced by gloo): same nlZ as the single-context path, one JSON line."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, GPAK_DIST_BACKEND="gloo", GPAK_DIST_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
+           "--steps", "2", "--warmup", "1", "--size", "4096", "--no-cpu"]
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["bytes_broadcast_per_step"] > 0
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--n",
+                             "4096", "--no-cpu"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    s = json.loads([l for l in single.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
