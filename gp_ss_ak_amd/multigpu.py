@@ -119,17 +119,24 @@ class HipEngine:
                                                   self._p(local), C.c_long(ld), Np, nb, P, rank, lb0, n_local,
                                                   last_width), "gpak_dev_update_cyclic")
 
-    def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out):
-        self._chk(self.lib.gpak_dev_trsv_fwd_block(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(inv),
-                                                   self._p(x), self._p(out)), "gpak_dev_trsv_fwd_block")
+    # row0: global row held in element 0 of each column of `blk` (0 = a full block column of the matrix; J for a
+    # packed panel that starts at its diagonal block).  The C-ABI addresses L[r, J+k] as blk[r + k*ld], so a packed
+    # panel is passed as a pointer shifted back by row0 elements (never dereferenced below the panel itself).
+    @staticmethod
+    def _pshift(t, row0):
+        return C.c_void_p(t.data_ptr() - 8 * int(row0))
 
-    def coldot(self, blk, ld, Np, J, W, x, s):
-        self._chk(self.lib.gpak_dev_coldot(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(x), self._p(s)),
-                  "gpak_dev_coldot")
+    def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out, row0=0):
+        self._chk(self.lib.gpak_dev_trsv_fwd_block(self._st(), self._pshift(blk, row0), C.c_long(ld), Np, J, W,
+                                                   self._p(inv), self._p(x), self._p(out)), "gpak_dev_trsv_fwd_block")
 
-    def trsv_bwd_block(self, blk, ld, J, W, inv, x, out):
-        self._chk(self.lib.gpak_dev_trsv_bwd_block(self._st(), self._p(blk), C.c_long(ld), J, W, self._p(inv),
-                                                   self._p(x), self._p(out)), "gpak_dev_trsv_bwd_block")
+    def coldot(self, blk, ld, Np, J, W, x, s, row0=0):
+        self._chk(self.lib.gpak_dev_coldot(self._st(), self._pshift(blk, row0), C.c_long(ld), Np, J, W, self._p(x),
+                                           self._p(s)), "gpak_dev_coldot")
+
+    def trsv_bwd_block(self, blk, ld, J, W, inv, x, out, row0=0):
+        self._chk(self.lib.gpak_dev_trsv_bwd_block(self._st(), self._pshift(blk, row0), C.c_long(ld), J, W,
+                                                   self._p(inv), self._p(x), self._p(out)), "gpak_dev_trsv_bwd_block")
 
     def logdiag_block(self, blk, ld, J, W, N, out):
         self._chk(self.lib.gpak_dev_logdiag_block(self._st(), self._p(blk), C.c_long(ld), J, W, N, self._p(out)),
@@ -186,6 +193,7 @@ class DistGP:
         self.alpha = engine.zeros(self.Np)
         self.params = None
         self.bytes_broadcast = 0
+        self.panels, self.invs = {}, {}   # pipelined schedule: every rank keeps every packed panel + inverses
         # sub-panel broadcasts pay off when there IS a transfer to hide; one rank keeps whole panels
         # (235.6 vs 231.0 ms at N=32768 on one GPU)
         self.pipeline = ((os.environ.get("GPAK_DIST_PIPELINE", "1") != "0" and self.P > 1) if pipeline is None
@@ -306,15 +314,17 @@ class DistGP:
     # quarters of the transfer under the owner's remaining factor work, and the next owner applies each
     # sub-panel to its column as it lands, so only the last quarter is exposed.
     def _produce(self, b):
-        """Factor block column b on its owner, 128 columns at a time; broadcast each sub-panel's rows below
-        the diagonal block as soon as they exist; the owner of b+1 applies them to its column as they
-        arrive.  Runs on the side stream.  Returns (packed panel or None, broadcast handles)."""
+        """Factor block column b on its owner, 128 columns at a time; broadcast each sub-panel -- rows from the
+        diagonal block down -- as soon as it exists; the owner of b+1 applies it to its column on arrival.
+        The inverted diagonal blocks follow in one small broadcast.  Every rank KEEPS the packed panel and the
+        inverses (N^2/2 doubles in total: 4.3 GB at N=32768), so that the two triangular solves afterwards need
+        no communication at all.  Runs on the side stream.  Returns (packed panel, broadcast handles)."""
         eng, ld, Np = self.eng, self.ld, self.Np
         J, W = self.start(b), self.width(b)
-        rows = Np - (J + W)
+        rows = Np - J                     # packed rows: global rows [J, Np), leading dimension rows
         own = self.rank == self.owner(b)
         nxt = b + 1
-        buf = eng.empty(W * rows) if rows > 0 else None
+        buf = eng.empty(W * rows)
         handles = []
         for s in range(W // TILE):
             if own:
@@ -325,20 +335,22 @@ class DistGP:
                 if rem > 0:  # the rest of the owner's own block column
                     eng.update_block(sub, ld, 0, TILE, self.blk[b][(s + 1) * TILE * ld:], ld, Np,
                                      J + (s + 1) * TILE, rem)
-                if rows > 0:
-                    buf[s * TILE * rows:(s + 1) * TILE * rows].view(TILE, rows).copy_(
-                        sub.view(TILE, ld)[:, J + W:Np])
-            if rows > 0:
-                chunk = buf[s * TILE * rows:(s + 1) * TILE * rows]
-                h = self._bcast(chunk, self.owner(b), async_op=True)
-                self.bytes_broadcast += chunk.numel() * 8
+                buf[s * TILE * rows:(s + 1) * TILE * rows].view(TILE, rows).copy_(sub.view(TILE, ld)[:, J:Np])
+            chunk = buf[s * TILE * rows:(s + 1) * TILE * rows]
+            h = self._bcast(chunk, self.owner(b), async_op=True)
+            self.bytes_broadcast += chunk.numel() * 8
+            if h is not None:
+                handles.append(h)
+            if nxt < self.nJ and self.rank == self.owner(nxt):
                 if h is not None:
-                    handles.append(h)
-                if nxt < self.nJ and self.rank == self.owner(nxt):
-                    if h is not None:
-                        h.wait()
-                    eng.update_block(chunk, rows, J + W, TILE, self.blk[nxt], ld, Np, self.start(nxt),
-                                     self.width(nxt))
+                    h.wait()
+                eng.update_block(chunk, rows, J, TILE, self.blk[nxt], ld, Np, self.start(nxt), self.width(nxt))
+        inv = self.inv[b] if own else eng.empty(W // TILE * 2 * TILE * TILE)
+        h = self._bcast(inv, self.owner(b), async_op=True)
+        self.bytes_broadcast += inv.numel() * 8
+        if h is not None:
+            handles.append(h)
+        self.panels[b], self.invs[b] = buf, inv
         return buf, handles
 
     def _factor_pipelined(self):
@@ -367,9 +379,7 @@ class DistGP:
             panel, handles = self._produce(0)
         for b in range(self.nJ):
             J, W = self.start(b), self.width(b)
-            rows = self.Np - (J + W)
-            if rows <= 0:
-                break
+            rows = self.Np - J            # the packed panel starts at its diagonal block (prow0 = J)
             nxt, nn = b + 1, b + 2
             # panel b is complete on this rank once its broadcasts (non-owners) / packs (owner) are done
             for h in handles:
@@ -377,18 +387,20 @@ class DistGP:
             if streams:
                 main.wait_stream(ps)
                 panel.record_stream(main)
+                self.invs[b].record_stream(main)
+            if nxt >= self.nJ:
+                break
             panel_next, handles_next = None, []
-            if nxt < self.nJ:
-                if streams:
-                    ps.wait_stream(main)  # bulk update b-1 has finished with block column b+2
-                with side:
-                    if nn < self.nJ and self.rank == self.owner(nn):
-                        self.eng.update_block(panel, rows, J + W, W, self.blk[nn], self.ld, self.Np,
-                                              self.start(nn), self.width(nn))
-                    panel_next, handles_next = self._produce(nxt)
+            if streams:
+                ps.wait_stream(main)  # bulk update b-1 has finished with block column b+2
+            with side:
+                if nn < self.nJ and self.rank == self.owner(nn):
+                    self.eng.update_block(panel, rows, J, W, self.blk[nn], self.ld, self.Np,
+                                          self.start(nn), self.width(nn))
+                panel_next, handles_next = self._produce(nxt)
             lb0 = next((i for i, c in enumerate(self.owned) if c > nn), None)
             if lb0 is not None:
-                self.eng.update_cyclic(panel, rows, J + W, W, self.local, self.ld, self.Np, self.nb, self.P,
+                self.eng.update_cyclic(panel, rows, J, W, self.local, self.ld, self.Np, self.nb, self.P,
                                        self.rank, lb0, len(self.owned), self.width(self.owned[-1]))
             panel, handles = panel_next, handles_next
         if streams:
@@ -399,6 +411,22 @@ class DistGP:
     def solve(self, rhs):
         """Returns B^-1 rhs (Np entries, replicated). rhs: replicated Np-vector (not modified)."""
         eng = self.eng
+        if self.pipeline:
+            # every rank holds every packed panel and inverse: both solves run locally, identically on all
+            # ranks, with no collective (solve_chol, GP_Utils.cpp:841-845)
+            xw, z = rhs.clone(), eng.zeros(self.Np)
+            for b in range(self.nJ):
+                J, W = self.start(b), self.width(b)
+                eng.trsv_fwd_block(self.panels[b], self.Np - J, self.Np, J, W, self.invs[b], xw, z, row0=J)
+            x = eng.zeros(self.Np)
+            s = eng.empty(self.nb)
+            for b in range(self.nJ - 1, -1, -1):
+                J, W = self.start(b), self.width(b)
+                if J + W < self.Np:
+                    eng.coldot(self.panels[b], self.Np - J, self.Np, J, W, x, s, row0=J)
+                    z[J:J + W] -= s[:W]
+                eng.trsv_bwd_block(self.panels[b], self.Np - J, J, W, self.invs[b], z, x, row0=J)
+            return x
         xw = rhs.clone() if self.rank == 0 else eng.zeros(self.Np)
         z = eng.zeros(self.Np)
         for b in range(self.nJ):

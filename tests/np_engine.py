@@ -90,8 +90,9 @@ class NumpyEngine:
             blk = local[lb * nb * ld: lb * nb * ld + Wc * ld]
             self.update_block(panel, ldp, prow0, W, blk, ld, Np, Jc, Wc)
 
-    def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out):
-        M = blk.numpy().reshape(W, ld).T
+    # row0: global row held in element 0 of each column (0: full block column; J: packed panel from its diagonal)
+    def trsv_fwd_block(self, blk, ld, Np, J, W, inv, x, out, row0=0):
+        M = self._rows_from(blk, W, ld, row0, Np)
         iv = inv.numpy().reshape(W // TILE, 2, TILE, TILE)
         xn, on = x.numpy(), out.numpy()
         for k in range(W // TILE):
@@ -100,12 +101,22 @@ class NumpyEngine:
             on[j0:j0 + TILE] = z
             xn[j0 + TILE:Np] -= M[j0 + TILE:Np, k * TILE:(k + 1) * TILE] @ z
 
-    def coldot(self, blk, ld, Np, J, W, x, s):
+    @staticmethod
+    def _rows_from(blk, W, ld, row0, Np):
+        """(Np x W) view-like array addressed by GLOBAL row; rows above row0 are never read by the callers."""
         M = blk.numpy().reshape(W, ld).T
+        if row0 == 0:
+            return M
+        full = np.zeros((Np, W))
+        full[row0:Np] = M[:Np - row0]
+        return full
+
+    def coldot(self, blk, ld, Np, J, W, x, s, row0=0):
+        M = self._rows_from(blk, W, ld, row0, Np)
         s.numpy()[:W] = M[J + W:Np, :].T @ x.numpy()[J + W:Np]
 
-    def trsv_bwd_block(self, blk, ld, J, W, inv, x, out):
-        M = blk.numpy().reshape(W, ld).T
+    def trsv_bwd_block(self, blk, ld, J, W, inv, x, out, row0=0):
+        M = self._rows_from(blk, W, ld, row0, J + W)
         iv = inv.numpy().reshape(W // TILE, 2, TILE, TILE)
         xn, on = x.numpy(), out.numpy()
         for k in range(W // TILE - 1, -1, -1):
