@@ -244,9 +244,16 @@ class DistGP:
             return None
         return self.eng.empty(W * rows) if rows > 0 else None
 
-    def factor(self):
-        """Returns 0, or the first failing column (1-based) like LAPACK dpotrf's info."""
-        return self._factor_pipelined() if self.pipeline else self._factor_whole_panels()
+    def factor(self, rhs=None):
+        """Returns 0, or the first failing column (1-based) like LAPACK dpotrf's info.  With `rhs` (pipelined
+        schedule) the forward substitution L^-1 rhs rides along: each rank applies panel b to its own copy right
+        after its bulk update, in the slack the serial panel chain leaves on the main stream."""
+        self._fwd = None
+        if self.pipeline:
+            if rhs is not None:
+                self._fwd = (rhs.clone(), self.eng.zeros(self.Np))
+            return self._factor_pipelined()
+        return self._factor_whole_panels()
 
     def _finish_info(self):
         torch = _torch()
@@ -389,6 +396,8 @@ class DistGP:
                 panel.record_stream(main)
                 self.invs[b].record_stream(main)
             if nxt >= self.nJ:
+                if self._fwd is not None:
+                    self.eng.trsv_fwd_block(panel, rows, self.Np, J, W, self.invs[b], self._fwd[0], self._fwd[1], row0=J)
                 break
             panel_next, handles_next = None, []
             if streams:
@@ -402,6 +411,8 @@ class DistGP:
             if lb0 is not None:
                 self.eng.update_cyclic(panel, rows, J, W, self.local, self.ld, self.Np, self.nb, self.P,
                                        self.rank, lb0, len(self.owned), self.width(self.owned[-1]))
+            if self._fwd is not None:
+                self.eng.trsv_fwd_block(panel, rows, self.Np, J, W, self.invs[b], self._fwd[0], self._fwd[1], row0=J)
             panel, handles = panel_next, handles_next
         if streams:
             main.wait_stream(ps)
@@ -414,10 +425,14 @@ class DistGP:
         if self.pipeline:
             # every rank holds every packed panel and inverse: both solves run locally, identically on all
             # ranks, with no collective (solve_chol, GP_Utils.cpp:841-845)
-            xw, z = rhs.clone(), eng.zeros(self.Np)
-            for b in range(self.nJ):
-                J, W = self.start(b), self.width(b)
-                eng.trsv_fwd_block(self.panels[b], self.Np - J, self.Np, J, W, self.invs[b], xw, z, row0=J)
+            if getattr(self, "_fwd", None) is not None:
+                z = self._fwd[1]          # L^-1 rhs was computed during the factorisation
+                self._fwd = None
+            else:
+                xw, z = rhs.clone(), eng.zeros(self.Np)
+                for b in range(self.nJ):
+                    J, W = self.start(b), self.width(b)
+                    eng.trsv_fwd_block(self.panels[b], self.Np - J, self.Np, J, W, self.invs[b], xw, z, row0=J)
             x = eng.zeros(self.Np)
             s = eng.empty(self.nb)
             for b in range(self.nJ - 1, -1, -1):
@@ -452,10 +467,11 @@ class DistGP:
         torch = _torch()
         e, bias, sn2, mode = self.params
         self.fill()
-        bad = self.factor()
+        rhs = self.y / sn2
+        bad = self.factor(rhs)
         if bad:
             return math.nan  # Chol_fail -> quiet NaN, GP_Utils.cpp:1145-1158
-        self.alpha = self.solve(self.y / sn2)  # alpha = (K + sn2 I)^-1 y
+        self.alpha = self.solve(rhs)  # alpha = (K + sn2 I)^-1 y
         # f = K*alpha: each rank sums over its slice of source points, then one all-reduce
         per = (self.N + self.P - 1) // self.P
         per = (per + 1) // 2 * 2
