@@ -52,6 +52,7 @@ struct gpak_ctx {
   int precision = GPAK_F64;
   hipStream_t stream = nullptr;     // main stream: fill, bulk trailing updates, solves
   hipStream_t stream_hi = nullptr;  // high-priority stream: panel factorisation (look-ahead)
+  hipStream_t stream_tail = nullptr;  // CU-masked copy of the main stream for the tail's bulk updates (optional)
   hipStream_t stream_fs = nullptr;  // forward substitution riding along with the factorisation, off the panel chain
   std::string err;
 

@@ -335,13 +335,14 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   const int init = 0x7fffffff;
   GPAK_HIP(hipMemcpyAsync(ctx->dInfo, &init, sizeof(int), hipMemcpyHostToDevice, su));
 
-  while ((int)ctx->ev_sync.size() < 2 * nJ + 3) {
+  while ((int)ctx->ev_sync.size() < 2 * nJ + 4) {
     hipEvent_t e;
     GPAK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->ev_sync.push_back(e);
   }
   hipEvent_t *EF = ctx->ev_sync.data(), *EU = ctx->ev_sync.data() + nJ;
   hipEvent_t Estart = ctx->ev_sync[2 * nJ], Eend = ctx->ev_sync[2 * nJ + 1], Efs = ctx->ev_sync[2 * nJ + 2];
+  hipEvent_t Eorder = ctx->ev_sync[2 * nJ + 3];
   // the panel stream starts after everything queued so far on the main stream (the fill)
   GPAK_HIP(hipEventRecord(Estart, su));
   GPAK_HIP(hipStreamWaitEvent(sp, Estart, 0));
@@ -369,6 +370,15 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
     if (b > 0) GPAK_HIP(hipStreamWaitEvent(sp, EU[b - 1], 0));
     update_cols(ctx, sp, J, W, J1, J2, false);
     if (J2 < Np) {
+      // chain-bound tail: the bulk update is off the critical path there; on the CU-masked stream it leaves
+      // idle compute units to potrf128 and the small panel products
+      static const int tail_rows = getenv("GPAK_TAIL_ROWS") ? atoi(getenv("GPAK_TAIL_ROWS")) : 12288;
+      hipStream_t su_b = (ctx->stream_tail && ctx->lookahead && Np - J2 <= tail_rows) ? ctx->stream_tail : ctx->stream;
+      if (su_b != su) {                       // keep the order of successive bulk updates across the two streams
+        GPAK_HIP(hipEventRecord(Eorder, su));
+        GPAK_HIP(hipStreamWaitEvent(su_b, Eorder, 0));
+        su = su_b;
+      }
       GPAK_HIP(hipStreamWaitEvent(su, EF[b], 0));
       if (ctx->profile) {
         while (ctx->ev_pool.size() < ev_used + 2) {
