@@ -2,6 +2,7 @@
 // block-column-cyclic multi-GPU factorisation runs on the block columns it owns.
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "../../include/gpak_dev.h"
 #include "gpak_internal.h"
@@ -126,6 +127,28 @@ int gpak_dev_nlz_terms(void *stream, int N, const double *y, const double *f, co
   // the launcher writes red[1], red[2]; shift so that they land in out[0], out[1]
   gpak_launch_nlz_terms((hipStream_t)stream, N, y, f, alpha, sn2, out - 1);
   return status();
+}
+
+int gpak_dev_stream_create(int skip_cus, void **stream_out) {
+  if (!stream_out || skip_cus < 0) return GPAK_EINVAL;
+  *stream_out = nullptr;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GPAK_EHIP;
+  hipStream_t s = nullptr;
+  if (skip_cus == 0 || skip_cus >= prop.multiProcessorCount) {
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return GPAK_EHIP;
+  } else {
+    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+    for (int c = 0; c < skip_cus; c++) mask[c / 32] &= ~(1u << (c % 32));
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) return GPAK_EHIP;
+  }
+  *stream_out = s;
+  return GPAK_OK;
+}
+
+int gpak_dev_stream_destroy(void *stream) {
+  return (stream && hipStreamDestroy((hipStream_t)stream) == hipSuccess) ? GPAK_OK : GPAK_EHIP;
 }
 
 }  // extern "C"

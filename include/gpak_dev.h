@@ -69,6 +69,13 @@ int gpak_dev_kmatvec(void *stream, const double *u, int cap, int n, int i0, int 
 int gpak_dev_nlz_terms(void *stream, int N, const double *y, const double *f, const double *alpha, double sn2,
                        double *out);
 
+/* A HIP stream that may not use the first skip_cus compute units (hipExtStreamCreateWithCUMask): the bulk
+ * updates of a rank run there, so that the serial panel chain (potrf128, the small panel products) always finds
+ * idle CUs beside them.  skip_cus = 0 gives an ordinary non-blocking stream.  Wrap it for torch with
+ * torch.cuda.ExternalStream.  *stream_out is a hipStream_t. */
+int gpak_dev_stream_create(int skip_cus, void **stream_out);
+int gpak_dev_stream_destroy(void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,8 +11,8 @@ from gp_ss_ak_amd import _lib, gpak
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "gpak.h")).read()
+def header_functions(name="gpak.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(gpak_[a-z0-9_]+)\s*\(", txt)))
 
@@ -24,8 +24,9 @@ def test_header_and_binding_list_the_same_symbols():
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    for name in header_functions():
+    for name in header_functions() + header_functions("gpak_dev.h"):
         assert hasattr(lib, name), name
+    assert len(header_functions("gpak_dev.h")) == 13       # the device-pointer level API of the multi-GPU path
 
 
 def test_header_is_plain_c():
