@@ -127,7 +127,8 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
     const int skip = tm ? atoi(tm) : 8;              // measured: 8 CUs, rows <= 12288: 183.4 -> 181.2 ms
     if (skip > 0 && skip < prop.multiProcessorCount) {
       std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
-      for (int c = 0; c < skip; c++) mask[c / 32] &= ~(1u << (c % 32));
+      const int stride = getenv("GPAK_TAIL_MASK_STRIDE") ? atoi(getenv("GPAK_TAIL_MASK_STRIDE")) : 1;
+      for (int c = 0; c < skip; c++) { const int bit = (c * stride) % prop.multiProcessorCount; mask[bit / 32] &= ~(1u << (bit % 32)); }
       if (hipExtStreamCreateWithCUMask(&ctx->stream_tail, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         ctx->stream_tail = nullptr;
         (void)hipGetLastError();
