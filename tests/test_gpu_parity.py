@@ -233,6 +233,55 @@ def test_four_column_inputs(gp, orc, mode):
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 127, 128, 129, 257])
+def test_edge_sizes(gp, orc, N):
+    """Sizes around the 128-tile padding, down to a single point; one test point; the reference's quirks of the
+    predictive variance (Q3: mask used as an index list, Q4: +sn2 skipped when sn2 == 1)."""
+    X, y = synth.drillholes(max(N, 4))
+    X, y = np.asfortranarray(X[:N]), y[:N].copy()
+    gp.set_train(X, y)
+    for sn2 in (SN2, 1.0):
+        gp.set_params(E, BIAS, sn2, gpak.DIST_DIRECT)
+        Ko = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+        assert rel(gp.gram(), Ko) <= 1e-13
+        info, alpha_o, Lo = orc.nlz_refseq(Ko, y, sn2)
+        nlz = gp.logLikelihood()
+        assert abs(nlz - info.nlz) <= 1e-10 * max(1.0, abs(info.nlz))
+        assert rel(gp.solve_alpha(), alpha_o) <= 1e-9
+        Xt = synth.test_points(1)
+        for compat in (0, 3):
+            mean, var = gp.posteriorMeanVar(Xt, compat=compat)
+            mo, vo = orc.predict(X, Xt, E, BIAS, sn2, alpha_o, Lo, orc.DIST_DIRECT, compat=compat)
+            assert rel(mean, mo) <= 1e-9 and np.abs(var - vo).max() <= 1e-9 * max(1.0, np.abs(vo).max())
+        g = gp.GradLL()
+        go = orc.grad_ref(X, y, Ko, Lo, alpha_o, E, BIAS, sn2, orc.DIST_DIRECT)
+        assert np.abs(g - go).max() <= 1e-8 * max(1.0, np.abs(go).max())
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+
+
+def test_coincident_points_and_ragged_batches(gp, orc):
+    """Duplicated sample locations (D2 = 0 off the diagonal: the dk = 0 branch of the gradient, Kernel.cpp:1179-1183)
+    and a prediction whose size is not a multiple of anything."""
+    N = 300
+    X, y = synth.drillholes(N)
+    X[150:160] = X[10:20]                      # ten coincident pairs
+    X = np.asfortranarray(X)
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    K, D2 = gp.gram(want_d2=True)
+    assert np.all(D2[150:160, 10:20].diagonal() == 0.0) and np.all(K[150:160, 10:20].diagonal() == E[6] ** 2 + BIAS)
+    Ko = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+    info, alpha_o, Lo = orc.nlz_refseq(Ko, y, SN2)
+    assert abs(gp.logLikelihood() - info.nlz) <= 1e-9 * abs(info.nlz)
+    g = gp.GradLL()
+    go = orc.grad_ref(X, y, Ko, Lo, alpha_o, E, BIAS, SN2, orc.DIST_DIRECT)
+    assert np.all(np.isfinite(g)) and np.abs(g - go).max() <= 1e-8 * np.abs(go).max()
+    Xt = synth.test_points(777)
+    mean, var = gp.posteriorMeanVar(Xt)
+    mo, vo = orc.predict(X, Xt, E, BIAS, SN2, alpha_o, Lo, orc.DIST_DIRECT)
+    assert rel(mean, mo) <= 1e-8 and rel(var, vo) <= 1e-8
+
+
 def test_options_and_two_live_contexts(orc):
     """gpak_set_option: every schedule variant gives the same numbers (look-ahead off = the classical order on
     one stream; other outer block sizes); value memoisation skips the rebuild only for bit-identical parameters;
