@@ -6,15 +6,17 @@
 // pre-inverted 128x128 diagonal block (alpha=1, beta=0), and the forward substitution
 // with many right-hand sides of _postVar (GP_Utils.cpp:991).
 //
-// Geometry: 128x128 output tile per workgroup, 4 waves (2x2), each wave 64x64 =
-// 4x4 v_mfma_f64_16x16x4_f64 accumulators; K staged 16 deep through double-buffered
-// LDS ([k][row] images, row stride 144 doubles so that the four k-planes a wave reads
-// per fragment land on disjoint bank halves).  All operands are column-major, so a
-// wave's global read of one k-column of a tile is 1 KiB contiguous (16 B per lane).
+// Three kernels, all 128x128 output tiles of 4x4 v_mfma_f64_16x16x4_f64 accumulators per wave:
+//   gpak_gemm_nt_f64_rs    (default)  operands streamed through registers, no LDS, no barriers
+//   gpak_gemm_nt_f64_rs32             the same with 32x32 per wave for small tile grids (panel chain)
+//   gpak_gemm_nt_f64       (GPAK_GEMM=lds, kept for comparison) K staged 16 deep through double-buffered
+//                          LDS with LDS-DMA ([k][row] images, row stride 144 doubles so that the four
+//                          k-planes a wave reads per fragment land on disjoint bank halves)
+// All operands are column-major, so one k-column of a tile is 1 KiB contiguous (16 B per lane).
 //
 // MFMA operand roles are swapped (the B-matrix fragment is the instruction's A operand):
 // the f64 16x16x4 result layout is col=lane&15,row=(lane>>4)+4*reg, so with the swap a
-// lane group writes 16 consecutive matrix rows (128 B) of one column.
+// lane group holds consecutive matrix rows of one column.
 #include <cstdlib>
 #include <cstring>
 
@@ -28,6 +30,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define KB 16
 #define LDS_LD 144
 
+// ---- LDS-staged kernel (GPAK_GEMM=lds) ---------------------------------------------------
 template <bool TRAILING>
 __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
                                                             const double *A, long lda, const double *B,
