@@ -282,6 +282,26 @@ def test_coincident_points_and_ragged_batches(gp, orc):
     assert rel(mean, mo) <= 1e-8 and rel(var, vo) <= 1e-8
 
 
+def test_alternative_kernels_give_the_same_step():
+    """The LDS-staged GEMM (GPAK_GEMM=lds), no CU-masked tail stream, everything on the 64x64-per-wave kernel:
+    same nlZ as the default build of the step (the environment is read once per process, hence subprocesses)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vals = {}
+    for name, env in (("default", {}), ("lds", {"GPAK_GEMM": "lds"}), ("nomask", {"GPAK_TAIL_MASK": "0"}),
+                      ("nosmall", {"GPAK_GEMM_SMALL": "0"})):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--size",
+                              "6000", "--no-cpu"], env=dict(os.environ, **env), cwd=root, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        vals[name] = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])["nlz"]
+    for name, v in vals.items():
+        assert abs(v - vals["default"]) <= 1e-11 * abs(vals["default"]), (name, vals)
+
+
 def test_options_and_two_live_contexts(orc):
     """gpak_set_option: every schedule variant gives the same numbers (look-ahead off = the classical order on
     one stream; other outer block sizes); value memoisation skips the rebuild only for bit-identical parameters;
