@@ -91,13 +91,14 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
       const double v = T[gpak_tix(kb, kb, l15, k)];
       a[k] = (l4 == 1) ? (k == l15 ? 1.0 : 0.0) : v;   // lanes 16..31: identity rows
     }
+    int bad = 16;   // first non-positive pivot of this block (branch-free: the 16 pivots stay ONE basic block,
+                    // so the scheduler can fill the rsq/Newton latency of pivot j+1 with the updates of pivot j)
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       double d = gpak_rdlane(a[j], j);
-      if (!(d > 0.0)) {
-        if (lane == 0) atomicMin(info, col0 + 16 * kb + j + 1);
-        d = 1.0;
-      }
+      const bool ok = d > 0.0;
+      bad = (!ok && bad == 16) ? j : bad;
+      d = ok ? d : 1.0;
       double r = __builtin_amdgcn_rsq(d);
       double h = d * r;
       double e = fma(-h, r, 1.0);
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
         a[k] = fma(-a[j], lk, a[k]);
       }
     }
+    if (bad < 16 && lane == 0) atomicMin(info, col0 + 16 * kb + bad + 1);
     if (l4 == 0) {
 #pragma unroll
       for (int k = 0; k < 16; k++)
