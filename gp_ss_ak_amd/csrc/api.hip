@@ -214,6 +214,8 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
   if (rc) return rc;
   GPAK_HIP(hipMemsetAsync(ctx->dX, 0, sizeof(double) * 4 * (size_t)Np, ctx->stream));
   GPAK_HIP(hipMemsetAsync(ctx->dy, 0, sizeof(double) * (size_t)Np, ctx->stream));
+  // the inverse blocks are triangular: zero once, potrf128 only writes inside the triangles
+  GPAK_HIP(hipMemsetAsync(ctx->dInv, 0, sizeof(double) * (size_t)T * 2 * GPAK_TILE * GPAK_TILE, ctx->stream));
   GPAK_HIP(hipMemsetAsync(ctx->dAlpha, 0, sizeof(double) * (size_t)Np, ctx->stream));
   for (int k = 0; k < d; k++)
     GPAK_HIP(hipMemcpyAsync(ctx->dX + (size_t)k * Np, X + (size_t)k * N, sizeof(double) * N,

@@ -54,7 +54,7 @@ int gpak_dev_factor_panel(void *stream, double *blk, long ld, int Np, int J, int
   // virtual bases: global (row, column) addressing that only ever touches columns [J, J+W)
   double *Mv = blk - (size_t)J * ld;
   double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
-  gpak_factor_panel((hipStream_t)stream, Mv, ld, Np, J, W, invv, info);
+  gpak_factor_panel((hipStream_t)stream, Mv, ld, Np, J, W, invv, info, true);  // caller's inv may be uninitialised
   return status();
 }
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ int gpak_tix(int rt, int ct, int i, int k) {
 //   col0   : global column of the block (for the not-positive-definite report)
 //   info   : atomicMin of the first failing column (1-based)
 __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv,
-                                                          int col0, int *info) {
+                                                          int col0, int *info, int zero_inv) {
   __shared__ double T[36 * 256];
   __shared__ double dd[8][16];
   // this workgroup is the serial link of the panel chain and shares its CU with two trailing-update
@@ -73,11 +73,14 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
   for (int it = 0; it < 32; it++) {
     const int e = t + 256 * it, r = (e & 63) * 2, c = e >> 6;
     const double2 z = make_double2(0.0, 0.0);
+    // zero_inv: the caller's inverse buffers are not known to be zero outside the triangles written at the
+    // end (the context's own are zeroed once in gpak_set_train: these 128 KiB of stores otherwise sit in
+    // front of every batch's vmcnt wait)
     if ((r >> 4) >= (c >> 4)) {
       const double2 v = *reinterpret_cast<const double2 *>(A + r + (size_t)c * ld);
       *reinterpret_cast<double2 *>(&T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)]) = v;
-      if ((r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;  // inv^T is upper
-    } else {
+      if (zero_inv && (r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;  // inv^T is upper
+    } else if (zero_inv) {
       *reinterpret_cast<double2 *>(inv + r + c * PB) = z;                            // inv is lower
     }
   }
@@ -266,18 +269,19 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
   }
 }
 
-void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info) {
-  hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(256), 0, st, A, ld, inv, col0, info);
+void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv) {
+  hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(256), 0, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
 }
 
 // Panel factorisation of one outer block column [J, J+W): all rows below it.
 // M is addressed with GLOBAL (row, column) indices; only columns [J, J+W) are touched, so a
 // rank that stores just this block column passes a virtual base (see dev_api.hip).
 // One level: 128-column steps, each followed by the K=128 update of the columns [j+128, J+W).
-static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info) {
+static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
+                             bool zero_inv) {
   for (int j = J; j < J + W; j += PB) {
     double *inv = inv_base + (size_t)(j / PB) * 2 * PB * PB;
-    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info);
+    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info, zero_inv);
     const int mt = (Np - j - PB) / PB;
     if (mt > 0) {
       double *P = M + (j + PB) + (size_t)j * ld;
@@ -292,10 +296,11 @@ static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, 
 // Panels wider than GPAK_PANEL_MID columns are factored in GPAK_PANEL_MID-column pieces with a K=MID update
 // of the rest of the panel in between (three-level blocking: 128 / MID / W).
 #define GPAK_PANEL_MID 512
-void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info) {
+void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
+                       bool zero_inv) {
   for (int j = J; j < J + W; j += GPAK_PANEL_MID) {
     const int w = (J + W - j) < GPAK_PANEL_MID ? (J + W - j) : GPAK_PANEL_MID;
-    factor_panel_128(st, M, ld, Np, j, w, inv_base, info);
+    factor_panel_128(st, M, ld, Np, j, w, inv_base, info, zero_inv);
     const int c0 = j + w, nct = (J + W - c0) / PB, mt = (Np - c0) / PB;
     if (nct > 0 && mt > 0) {
       const double *P = M + c0 + (size_t)j * ld;
@@ -304,7 +309,8 @@ void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W,
   }
 }
 static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W) {
-  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo);
+  // ctx->dInv is zeroed once in gpak_set_train and only ever written inside its triangles
+  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false);
 }
 
 // Update of the columns [c0, c1) (and all rows >= c0) with the factored panel [J, J+W).
