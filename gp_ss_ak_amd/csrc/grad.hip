@@ -129,15 +129,15 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
           }
           d2m[m] = d2;
           d2s += d2;
-          kfull += kp.term[m].var2 * (kp.term[m].profile == GPAK_PROFILE_RBF ? exp(-0.5 * kp.term[m].iw * d2)
-                                                                            : exp(-1.0 * sqrt(d2)));
+          kfull += kp.term[m].var2 * gpak_exp_nonpos(kp.term[m].profile == GPAK_PROFILE_RBF ? -0.5 * kp.term[m].iw * d2
+                                                                                            : -gpak_sqrt_nonneg(d2));
         }
         const double qw = q * (1.0 / gc.sn2) - pal[h] * cal[jl];   // dhyp, GP_Utils.cpp:1168
         acc[7] = fma(wgt * q, kfull, acc[7]);                       // sum(Q % K), GP_Utils.cpp:1206
         if (i == j) acc[8] += qw;                                   // trace(QW), Kernel.cpp:370-377
         if (te >= 0) {
-          const double sd = sqrt(d2m[te]);                          // Kernel.cpp:1178
-          const double ek = exp(-1.0 * sd);                         // KD2, :1176
+          const double sd = gpak_sqrt_nonneg(d2m[te]);              // Kernel.cpp:1178
+          const double ek = gpak_exp_nonpos(-sd);                   // KD2, :1176
           const double dk = (sd == 0.0 || i == j) ? 0.0 : ek * (-0.5 / sd);  // :1179-1184
           const double rm = gc.var2 * qw * dk;                      // R = Qs % dk, :927, :1185
 #pragma unroll
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
         for (int m = 0; m < GPAK_MAX_TERMS; m++) {
           if (m >= nterms) break;
           if (gc.kinds[m] == GPAK_KERN_EXP) {                       // Kernel.cpp:644-693 on the summed D2
-            const double sd = sqrt(d2s), kd = exp(-1.0 * sd);
+            const double sd = gpak_sqrt_nonneg(d2s), kd = gpak_exp_nonpos(-sd);
             const double dk = (sd == 0.0 || i == j) ? 0.0 : kd * (-0.5 / sd);
             acc[9 + 2 * m] = fma(wgt * qw * dk, d2s, acc[9 + 2 * m]);
             acc[10 + 2 * m] = fma(wgt * qw * kd, kd, acc[10 + 2 * m]);
           } else if (gc.kinds[m] == GPAK_KERN_RBF) {                // Kernel.cpp:491-540 on the summed D2
-            const double kd = exp(-0.5 * kp.term[m].iw * d2s);
+            const double kd = gpak_exp_nonpos(-0.5 * kp.term[m].iw * d2s);
             acc[9 + 2 * m] = fma(wgt * qw * kd, d2s, acc[9 + 2 * m]);
             acc[10 + 2 * m] = fma(wgt * qw, kd, acc[10 + 2 * m]);
           }

@@ -53,7 +53,7 @@ __device__ __forceinline__ double gpak_d2(double p0, double p1, double p2, doubl
 }
 // var2 * profile(D2): Kernel.cpp:881 (ExpAns / Exp), :487 (RBF)
 __device__ __forceinline__ double gpak_profile(double d2, const KernTerm &t) {
-  return t.var2 * (t.profile == GPAK_PROFILE_RBF ? exp(-0.5 * t.iw * d2) : exp(-1.0 * sqrt(d2)));
+  return t.var2 * gpak_exp_nonpos(t.profile == GPAK_PROFILE_RBF ? -0.5 * t.iw * d2 : -gpak_sqrt_nonneg(d2));
 }
 
 // ---------------------------------------------------------------------------------------
