@@ -32,7 +32,23 @@ static KernParams make_kp(const double *expans, double bias, int mode, const dou
 }
 static int status() { return hipGetLastError() == hipSuccess ? GPAK_OK : GPAK_EHIP; }
 
+__global__ void gpak_pack_f64(const double *__restrict__ src, long ld, int row0, int nrows, double *__restrict__ dst) {
+  const int c = blockIdx.y;
+  const int r = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (r < nrows)   // nrows, row0, ld are even: 16-B accesses
+    *reinterpret_cast<double2 *>(dst + (size_t)c * nrows + r) =
+        *reinterpret_cast<const double2 *>(src + (size_t)c * ld + row0 + r);
+}
+
 extern "C" {
+
+int gpak_dev_pack(void *stream, const double *src, long ld, int row0, int nrows, int ncols, double *dst) {
+  if (nrows <= 0 || ncols <= 0) return GPAK_OK;
+  if ((nrows | row0 | ld) & 1) return GPAK_EINVAL;
+  hipLaunchKernelGGL(gpak_pack_f64, dim3((nrows / 2 + 255) / 256, ncols), dim3(256), 0, (hipStream_t)stream, src, ld, row0,
+                     nrows, dst);
+  return status();
+}
 
 int gpak_dev_transform(void *stream, const double *x, int xs, int n, int cap, const double *expans,
                        const double *mu, double *u) {

@@ -50,11 +50,12 @@ class HipEngine:
         for name in ("gpak_dev_transform", "gpak_dev_fill_b", "gpak_dev_factor_panel", "gpak_dev_update_block",
                      "gpak_dev_update_cyclic", "gpak_dev_trsv_fwd_block", "gpak_dev_coldot", "gpak_dev_trsv_bwd_block",
                      "gpak_dev_logdiag_block", "gpak_dev_kmatvec", "gpak_dev_nlz_terms", "gpak_dev_stream_create",
-                     "gpak_dev_stream_destroy"):
+                     "gpak_dev_stream_destroy", "gpak_dev_pack"):
             if not hasattr(self.lib, name):
                 raise RuntimeError(f"libgpak_hip.so lacks {name}")
             getattr(self.lib, name).restype = C.c_int
         self._host_e = None
+        self._cur = None   # cuda_stream handle of the stream the engine launches on (None: ask torch)
 
     # -- memory ------------------------------------------------------------------------------
     def empty(self, n, dtype=None):
@@ -93,7 +94,32 @@ class HipEngine:
         return self._bulk
 
     def _st(self):
-        return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+        # torch.cuda.current_stream() costs ~7 us of host time per call; the schedule makes ~800 engine calls per
+        # step, so the handle of the stream last entered through `on()` is cached
+        if self._cur is None:
+            self._cur = _torch().cuda.current_stream().cuda_stream
+        return C.c_void_p(self._cur)
+
+    def on(self, stream):
+        """Context manager: make `stream` torch's current stream AND the stream of the engine's launches."""
+        eng, torch = self, _torch()
+
+        class _ctx:
+            def __enter__(c):
+                c.prev = eng._cur
+                c.t = torch.cuda.stream(stream)
+                c.t.__enter__()
+                eng._cur = stream.cuda_stream
+
+            def __exit__(c, *a):
+                c.t.__exit__(*a)
+                eng._cur = c.prev
+        return _ctx()
+
+    def pack(self, src, ld, row0, nrows, ncols, dst):
+        """dst (nrows x ncols, packed) <- rows [row0, row0+nrows) of the ncols columns of src (leading dimension ld)."""
+        self._chk(self.lib.gpak_dev_pack(self._st(), self._p(src), C.c_long(ld), int(row0), int(nrows), int(ncols),
+                                         self._p(dst)), "gpak_dev_pack")
 
     @staticmethod
     def _p(t):
@@ -300,7 +326,7 @@ class DistGP:
                 # before its bulk update, so the transfer overlaps the MFMA work of step b
                 if streams:
                     ps.wait_stream(main)  # panel b is complete, earlier bulk updates of blk[nxt] are queued
-                    ctx = torch.cuda.stream(ps)
+                    ctx = self.eng.on(ps)
                     ctx.__enter__()
                 try:
                     if self.rank == self.owner(nxt):
@@ -354,7 +380,7 @@ class DistGP:
                 if rem > 0:  # the rest of the owner's own block column
                     eng.update_block(sub, ld, 0, TILE, self.blk[b][(s + 1) * TILE * ld:], ld, Np,
                                      J + (s + 1) * TILE, rem)
-                buf[s * TILE * rows:(s + 1) * TILE * rows].view(TILE, rows).copy_(sub.view(TILE, ld)[:, J:Np])
+                eng.pack(sub, ld, J, rows, TILE, buf[s * TILE * rows:(s + 1) * TILE * rows])
             chunk = buf[s * TILE * rows:(s + 1) * TILE * rows]
             h = self._bcast(chunk, self.owner(b), async_op=True)
             self.bytes_broadcast += chunk.numel() * 8
@@ -385,7 +411,7 @@ class DistGP:
         class _side:  # `with side:` = queue on the panel stream when the engine has streams
             def __enter__(s2):
                 if streams:
-                    s2.c = torch.cuda.stream(ps)
+                    s2.c = self.eng.on(ps)
                     s2.c.__enter__()
 
             def __exit__(s2, *a):
@@ -483,7 +509,7 @@ class DistGP:
             torch = _torch()
             bulk = self.eng.bulk_stream(int(os.environ.get("GPAK_DIST_MASK", "8")))
             bulk.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(bulk):
+            with self.eng.on(bulk):
                 v = self._nlz()
             torch.cuda.current_stream().wait_stream(bulk)
             return v

@@ -69,6 +69,10 @@ int gpak_dev_kmatvec(void *stream, const double *u, int cap, int n, int i0, int 
 int gpak_dev_nlz_terms(void *stream, int N, const double *y, const double *f, const double *alpha, double sn2,
                        double *out);
 
+/* dst (nrows x ncols doubles, packed column-major) <- rows [row0, row0+nrows) of ncols columns of src (leading
+ * dimension ld): the panel pack in front of a broadcast. */
+int gpak_dev_pack(void *stream, const double *src, long ld, int row0, int nrows, int ncols, double *dst);
+
 /* A HIP stream that may not use the first skip_cus compute units (hipExtStreamCreateWithCUMask): the bulk
  * updates of a rank run there, so that the serial panel chain (potrf128, the small panel products) always finds
  * idle CUs beside them.  skip_cus = 0 gives an ordinary non-blocking stream.  Wrap it for torch with

@@ -77,6 +77,9 @@ class NumpyEngine:
             iv[k, 0] = X.T   # stored column-major: memory [c][r] = X[r][c]
             iv[k, 1] = X     # inverse transpose, column-major
 
+    def pack(self, src, ld, row0, nrows, ncols, dst):
+        dst.view(ncols, nrows).copy_(src.view(ncols, ld)[:, row0:row0 + nrows])
+
     def update_block(self, panel, ldp, prow0, W, blk, ld, Np, Jc, Wc):
         P = panel.numpy().reshape(W, ldp).T
         C = blk.numpy().reshape(Wc, ld).T
