@@ -123,6 +123,15 @@ int gpak_dev_trsv_bwd_block(void *stream, const double *blk, long ld, int J, int
   return status();
 }
 
+int gpak_dev_trsv_bwd_packed(void *stream, const double *panel, long ldp, int row0, int Np, int J, int W,
+                             const double *inv, const double *z, double *scratch, double *out) {
+  if (W <= 0 || W > 512 || (W % GPAK_TILE)) return GPAK_EINVAL;
+  const double *Lv = panel - row0 - (size_t)J * ldp;   // L[r, c] = Lv[r + c * ldp], global r and c
+  const double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
+  gpak_launch_trsv_bwd_block2((hipStream_t)stream, Np, J, W, Lv, ldp, invv, z, out, scratch);
+  return status();
+}
+
 int gpak_dev_logdiag_block(void *stream, const double *blk, long ld, int J, int W, int N, double *out) {
   const double *Lv = blk - (size_t)J * ld;
   gpak_launch_logdiag_block((hipStream_t)stream, J, W, N, Lv, ld, out);

@@ -227,6 +227,8 @@ void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W,
 void gpak_launch_trsv_fwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,
                           double *out);
 // two-level variant: z is read-only, scratch holds 8 * 512 doubles
+void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const double *L, long ld, const double *inv,
+                                 const double *z, double *out, double *scratch);
 void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
                            double *out, double *scratch);
 void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,

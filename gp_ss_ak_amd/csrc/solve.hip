@@ -203,22 +203,29 @@ __global__ __launch_bounds__(1024) void gpak_trsv_bwd_diag_f64(int J, int W, con
   }
 }
 
+// one block column [J, J+W), W <= 512.  scratch: 8 * 512 doubles
+void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const double *L, long ld, const double *inv,
+                                 const double *z, double *out, double *scratch) {
+  const int NB = BD_MAXW, rows = Np - (J + W);
+  int R = 0, per = 0;
+  if (rows > 0) {
+    R = (rows + 4095) / 4096;
+    if (R > 8) R = 8;
+    per = ((rows + R - 1) / R + 127) / 128 * 128;
+    hipLaunchKernelGGL(gpak_coldot_split_f64, dim3(W / 4, R), dim3(256), 0, st, Np, J + W, J, W, per, L, ld, out, scratch,
+                       NB);
+  }
+  hipLaunchKernelGGL(gpak_trsv_bwd_diag_f64, dim3(1), dim3(1024), 0, st, J, W, L, ld, inv, z, scratch, R, NB, out);
+}
+
 // scratch: 8 * 512 doubles
 void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
                            double *out, double *scratch) {
   const int NB = BD_MAXW;
   const int nJ = (Np + NB - 1) / NB;
   for (int b = nJ - 1; b >= 0; b--) {
-    const int J = b * NB, W = min(NB, Np - J), rows = Np - (J + W);
-    int R = 0, per = 0;
-    if (rows > 0) {
-      R = (rows + 4095) / 4096;
-      if (R > 8) R = 8;
-      per = ((rows + R - 1) / R + 127) / 128 * 128;
-      hipLaunchKernelGGL(gpak_coldot_split_f64, dim3(W / 4, R), dim3(256), 0, st, Np, J + W, J, W, per, L, ld, out,
-                         scratch, NB);
-    }
-    hipLaunchKernelGGL(gpak_trsv_bwd_diag_f64, dim3(1), dim3(1024), 0, st, J, W, L, ld, inv, z, scratch, R, NB, out);
+    const int J = b * NB, W = min(NB, Np - J);
+    gpak_launch_trsv_bwd_block2(st, Np, J, W, L, ld, inv, z, out, scratch);
   }
 }
 

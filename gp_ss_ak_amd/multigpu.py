@@ -50,7 +50,7 @@ class HipEngine:
         for name in ("gpak_dev_transform", "gpak_dev_fill_b", "gpak_dev_factor_panel", "gpak_dev_update_block",
                      "gpak_dev_update_cyclic", "gpak_dev_trsv_fwd_block", "gpak_dev_coldot", "gpak_dev_trsv_bwd_block",
                      "gpak_dev_logdiag_block", "gpak_dev_kmatvec", "gpak_dev_nlz_terms", "gpak_dev_stream_create",
-                     "gpak_dev_stream_destroy", "gpak_dev_pack"):
+                     "gpak_dev_stream_destroy", "gpak_dev_pack", "gpak_dev_trsv_bwd_packed"):
             if not hasattr(self.lib, name):
                 raise RuntimeError(f"libgpak_hip.so lacks {name}")
             getattr(self.lib, name).restype = C.c_int
@@ -175,6 +175,11 @@ class HipEngine:
     def trsv_bwd_block(self, blk, ld, J, W, inv, x, out, row0=0):
         self._chk(self.lib.gpak_dev_trsv_bwd_block(self._st(), self._pshift(blk, row0), C.c_long(ld), J, W,
                                                    self._p(inv), self._p(x), self._p(out)), "gpak_dev_trsv_bwd_block")
+
+    def trsv_bwd_packed(self, panel, ldp, row0, Np, J, W, inv, z, scratch, out):
+        self._chk(self.lib.gpak_dev_trsv_bwd_packed(self._st(), self._p(panel), C.c_long(ldp), int(row0), Np, J, W,
+                                                    self._p(inv), self._p(z), self._p(scratch), self._p(out)),
+                  "gpak_dev_trsv_bwd_packed")
 
     def logdiag_block(self, blk, ld, J, W, N, out):
         self._chk(self.lib.gpak_dev_logdiag_block(self._st(), self._p(blk), C.c_long(ld), J, W, N, self._p(out)),
@@ -472,13 +477,10 @@ class DistGP:
                     J, W = self.start(b), self.width(b)
                     eng.trsv_fwd_block(self.panels[b], self.Np - J, self.Np, J, W, self.invs[b], xw, z, row0=J)
             x = eng.zeros(self.Np)
-            s = eng.empty(self.nb)
+            scratch = eng.empty(8 * 512)
             for b in range(self.nJ - 1, -1, -1):
                 J, W = self.start(b), self.width(b)
-                if J + W < self.Np:
-                    eng.coldot(self.panels[b], self.Np - J, self.Np, J, W, x, s, row0=J)
-                    z[J:J + W] -= s[:W]
-                eng.trsv_bwd_block(self.panels[b], self.Np - J, J, W, self.invs[b], z, x, row0=J)
+                eng.trsv_bwd_packed(self.panels[b], self.Np - J, J, self.Np, J, W, self.invs[b], z, scratch, x)
             return x
         xw = rhs.clone() if self.rank == 0 else eng.zeros(self.Np)
         z = eng.zeros(self.Np)

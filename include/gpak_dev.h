@@ -58,6 +58,12 @@ int gpak_dev_coldot(void *stream, const double *blk, long ld, int Np, int J, int
 /* out[J..J+W) = L_bb^-T x[J..J+W)  (x[J..J+W) is overwritten with intermediates) */
 int gpak_dev_trsv_bwd_block(void *stream, const double *blk, long ld, int J, int W, const double *inv, double *x,
                             double *out);
+/* Back substitution step for block column [J, J+W) held as a PACKED panel (element 0 of each column = global row
+ * row0, leading dimension ldp):  out[J..J+W) = L_bb^-T ( z[J..J+W) - sum_{r >= J+W} L[r, J..J+W) out[r] ).
+ * z is read-only; scratch holds 8*512 doubles; W <= 512.  Two launches (streamed column dots + one workgroup
+ * for the diagonal block). */
+int gpak_dev_trsv_bwd_packed(void *stream, const double *panel, long ldp, int row0, int Np, int J, int W,
+                             const double *inv, const double *z, double *scratch, double *out);
 /* out[0] = sum of log L[c,c] over the valid (c < N) columns of the block column */
 int gpak_dev_logdiag_block(void *stream, const double *blk, long ld, int J, int W, int N, double *out);
 

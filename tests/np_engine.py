@@ -129,6 +129,14 @@ class NumpyEngine:
             if k > 0:
                 xn[J:j0] -= M[j0:j0 + TILE, :k * TILE].T @ w
 
+    def trsv_bwd_packed(self, panel, ldp, row0, Np, J, W, inv, z, scratch, out):
+        s = torch.zeros(W, dtype=torch.float64)
+        if J + W < Np:
+            self.coldot(panel, ldp, Np, J, W, out, s, row0=row0)
+        v = z.clone()
+        v[J:J + W] -= s
+        self.trsv_bwd_block(panel, ldp, J, W, inv, v, out, row0=row0)
+
     def logdiag_block(self, blk, ld, J, W, N, out):
         M = blk.numpy().reshape(W, ld).T
         nc = max(0, min(W, N - J))
