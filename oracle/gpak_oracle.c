@@ -162,6 +162,10 @@ void orc_mahadist(const double *X1, int n, const double *X2, int m, int d, const
   free(U); free(V);
 }
 
+/* OpenMP team size of this library's own loops (the default is one thread per visible core: on a box whose
+ * cgroup grants 16 of 128+ cores that is a heavily oversubscribed team -- seconds per call at N = 1). */
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+
 /* ParamKer packing of Kern_ExpAnisotropic::computeK, Kernel.cpp:864-878 */
 static void pack_paramker(const double *e, double *par) {
   par[0] = e[0]; par[1] = e[2]; par[2] = e[4];

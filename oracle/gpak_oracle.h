@@ -37,6 +37,8 @@ extern "C" {
  * Returns 0 when all symbols were bound, non-zero otherwise (in-repo blocked C
  * fallback stays active).  threads<=0 leaves the library default. */
 int orc_use_lapack(const char *so_path, int threads);
+/* team size of the oracle's own OpenMP loops (oracle.py sets min(usable CPUs, 16) on load) */
+void orc_set_threads(int n);
 int orc_lapack_active(void);
 
 /* sigInv = Rot * diag(L) * Rot^T  (Kernel.cpp:1399-1425).  par = ParamKer =

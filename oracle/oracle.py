@@ -44,6 +44,12 @@ def lib():
         _LIB.orc_use_lapack.restype = C.c_int
         _LIB.orc_potrf_lower.restype = C.c_int
         _LIB.orc_kdiag.restype = C.c_double
+        # a team per visible core oversubscribes a cgroup-limited box by 8x and makes every call take seconds
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except AttributeError:
+            usable = os.cpu_count() or 1
+        _LIB.orc_set_threads(C.c_int(max(1, min(usable, int(os.environ.get("GPAK_ORACLE_THREADS", "16"))))))
     return _LIB
 
 
