@@ -41,7 +41,7 @@ def test_gram_matches_oracle(gp, orc, N, mode):
     assert np.array_equal(K, K.T)
 
 
-@pytest.mark.parametrize("N", [8, 64, 200, 512, 1000, 2048])
+@pytest.mark.parametrize("N", [8, 64, 200, 512, 1000, 2048, 4096, 6000])
 def test_factor_alpha_nlz_match_oracle(gp, orc, N):
     X, y = synth.drillholes(N)
     gp.set_train(X, y)
@@ -64,7 +64,7 @@ def test_factor_alpha_nlz_match_oracle(gp, orc, N):
     assert abs(slp - info.sumlp) <= 1e-9 * abs(info.sumlp)
 
 
-@pytest.mark.parametrize("N,M", [(64, 16), (512, 16), (1000, 300)])
+@pytest.mark.parametrize("N,M", [(64, 16), (512, 16), (1000, 300), (4096, 1000)])
 def test_predict_matches_oracle(gp, orc, N, M):
     X, y = synth.drillholes(N)
     Xte = synth.test_points(M)
@@ -97,7 +97,7 @@ def test_not_positive_definite_reports_chol_fail(gp):
     assert gp.factor()
 
 
-@pytest.mark.parametrize("N", [64, 512, 1000])
+@pytest.mark.parametrize("N", [64, 512, 1000, 2500])
 @pytest.mark.parametrize("mode", [gpak.DIST_DIRECT, gpak.DIST_EXPANSION])
 def test_reference_style_gradient_matches_oracle(gp, orc, N, mode):
     """GradLL + getGradients as written (not the true gradient: SURVEY.md 8(f-1))."""

@@ -84,7 +84,8 @@ def test_single_process_schedule_matches_oracle(orc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,n,nb,pipeline", [(1, 1000, 256, 1), (2, 1500, 256, 1), (2, 1100, 512, 1),
-                                                  (3, 2500, 256, 1), (2, 1500, 256, 0)])
+                                                  (3, 2500, 256, 1), (2, 1500, 256, 0), (2, 5000, 512, 1),
+                                                  (4, 6000, 512, 1), (3, 4100, 512, 0)])
 def test_hip_engine_schedule_matches_oracle(orc, world, n, nb, pipeline):
     res = run_world(world, n, nb, engine="hip", pipeline=pipeline)
     info, alpha = oracle_ref(orc, n)
