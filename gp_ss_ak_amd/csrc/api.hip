@@ -71,11 +71,12 @@ static void release_train(gpak_ctx *ctx) {
   if (ctx->dy) hipFree(ctx->dy);
   if (ctx->dM) hipFree(ctx->dM);
   if (ctx->dInv) hipFree(ctx->dInv);
+  if (ctx->dInv512) hipFree(ctx->dInv512);
   if (ctx->dAlpha) hipFree(ctx->dAlpha);
   if (ctx->dWork) hipFree(ctx->dWork);
   if (ctx->dF) hipFree(ctx->dF);
   gpak_grad_release(ctx);
-  ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dAlpha = ctx->dWork = ctx->dF = nullptr;
+  ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dInv512 = ctx->dAlpha = ctx->dWork = ctx->dF = nullptr;
   free_points(ctx->U);
   if (ctx->dLf) hipFree(ctx->dLf);
   if (ctx->dInvf) hipFree(ctx->dInvf);
@@ -203,6 +204,7 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
       hipMalloc(&ctx->dy, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dM, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
       hipMalloc(&ctx->dInv, sizeof(double) * (size_t)T * 2 * GPAK_TILE * GPAK_TILE) != hipSuccess ||
+      hipMalloc(&ctx->dInv512, sizeof(double) * (size_t)((Np + 511) / 512) * 512 * 512) != hipSuccess ||
       hipMalloc(&ctx->dAlpha, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dF, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dWork, sizeof(double) * 70 * (size_t)Np) != hipSuccess) {
@@ -326,6 +328,7 @@ static int ensure_factor(gpak_ctx *ctx) {
                    ctx->ld, nullptr);
   ctx->mstate = gpak_ctx::M_B;
   ctx->z_ok = false;
+  ctx->inv512_ok = false;
   ctx->lf_ok = false;
   if (ctx->fwd_in_factor) gpak_launch_scale(st, ctx->Np, ctx->dy, 1.0 / ctx->sn2, ctx->dWork);  // rhs = y/sn2
   GPAK_HIP(hipEventRecord(ctx->ev[1], st));
@@ -346,6 +349,7 @@ static int ensure_factor(gpak_ctx *ctx) {
   if (rc) return rc;
   ctx->mstate = gpak_ctx::M_L;
   ctx->z_ok = ctx->fwd_in_factor;
+  ctx->inv512_ok = ctx->fwd_in_factor && !(getenv("GPAK_INV512") && atoi(getenv("GPAK_INV512")) == 0);
   return GPAK_OK;
 }
 
@@ -362,7 +366,8 @@ static int ensure_alpha(gpak_ctx *ctx) {
     gpak_launch_trsv_fwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
   }
   ctx->z_ok = false;  // the back substitution consumes w1
-  gpak_launch_trsv_bwd2(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha, ctx->dWork + 2 * (size_t)ctx->Np);
+  gpak_launch_trsv_bwd2(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha, ctx->dWork + 2 * (size_t)ctx->Np,
+                        ctx->inv512_ok ? ctx->dInv512 : nullptr);
   GPAK_HIP(hipEventRecord(ctx->ev[4], st));
   GPAK_HIP(hipEventSynchronize(ctx->ev[4]));
   float ms = 0;

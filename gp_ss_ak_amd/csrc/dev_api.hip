@@ -124,11 +124,20 @@ int gpak_dev_trsv_bwd_block(void *stream, const double *blk, long ld, int J, int
 }
 
 int gpak_dev_trsv_bwd_packed(void *stream, const double *panel, long ldp, int row0, int Np, int J, int W,
-                             const double *inv, const double *z, double *scratch, double *out) {
+                             const double *inv, const double *z, double *scratch, double *out, const double *rinv) {
   if (W <= 0 || W > 512 || (W % GPAK_TILE)) return GPAK_EINVAL;
   const double *Lv = panel - row0 - (size_t)J * ldp;   // L[r, c] = Lv[r + c * ldp], global r and c
   const double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
-  gpak_launch_trsv_bwd_block2((hipStream_t)stream, Np, J, W, Lv, ldp, invv, z, out, scratch);
+  gpak_launch_trsv_bwd_block2((hipStream_t)stream, Np, J, W, Lv, ldp, invv, z, out, scratch, rinv);
+  return status();
+}
+
+int gpak_dev_diag_inverse(void *stream, const double *panel, long ldp, int row0, int J, int W, const double *inv,
+                          double *rinv) {
+  if (W <= 0 || W > 512 || (W % GPAK_TILE) || !rinv) return GPAK_EINVAL;
+  const double *Lv = panel - row0 - (size_t)J * ldp;
+  const double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
+  gpak_launch_diag_inverse((hipStream_t)stream, J, W, Lv, ldp, invv, rinv);
   return status();
 }
 

@@ -77,6 +77,8 @@ struct gpak_ctx {
   DevPoints U;               // transformed training points
   double *dM = nullptr;      // Np x ld matrix buffer: B then L (lower)
   double *dInv = nullptr;    // (Np/128) inverted 128x128 diagonal blocks of L
+  double *dInv512 = nullptr; // (Np/512) explicit (L_bb^-1)^T of the 512x512 diagonal blocks (back substitution)
+  bool inv512_ok = false;
   double *dAlpha = nullptr;  // Np
   double *dWork = nullptr;   // 4*Np scratch vectors
   double *dRed = nullptr;    // small reduction scratch
@@ -228,9 +230,11 @@ void gpak_launch_trsv_fwd(hipStream_t st, int Np, const double *L, long ld, cons
                           double *out);
 // two-level variant: z is read-only, scratch holds 8 * 512 doubles
 void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const double *L, long ld, const double *inv,
-                                 const double *z, double *out, double *scratch);
+                                 const double *z, double *out, double *scratch, const double *Rinv = nullptr);
+// R = (L_bb^-1)^T of the W x W diagonal block at J (W <= 512), column-major ld 512; seven small GEMM launches
+void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R);
 void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
-                           double *out, double *scratch);
+                           double *out, double *scratch, const double *Rinv512 = nullptr);
 void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,
                           double *out);
 void gpak_launch_trsv_fwd_block(hipStream_t st, int Np, int J, int W, const double *L, long ld,

@@ -11,6 +11,8 @@
 //       [gemm_nt]   update of the remaining columns of the outer block (K = 128)
 //     [gemm_nt]     trailing update of everything right of the outer block (K = nb_outer):
 //                   the N^3/3 term, MFMA-bound.
+#include <algorithm>
+
 #include "gpak_internal.h"
 
 #define PB 128
@@ -368,6 +370,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   GPAK_HIP(hipStreamWaitEvent(sp, Estart, 0));
 
   size_t ev_used = 0;
+  int done512 = 0;
   double tflops = 0.0;
   int tl = 0;
   for (int b = 0; b < nJ; b++) {
@@ -380,6 +383,15 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
     if (ctx->fwd_in_factor) {
       if (sf != sp) GPAK_HIP(hipStreamWaitEvent(sf, EF[b], 0));
       gpak_launch_trsv_fwd_block(sf, Np, J, W, ctx->dM, ctx->ld, ctx->dInv, ctx->dWork, ctx->dWork + Np);
+      // explicit inverses of the 512-column diagonal blocks completed by this panel, for the back substitution
+      // (same stream: off the panel chain, hidden behind the bulk updates)
+      static const bool inv512 = !(getenv("GPAK_INV512") && atoi(getenv("GPAK_INV512")) == 0);
+      while (inv512 && done512 * 512 < Np && (std::min(Np, (done512 + 1) * 512) <= J + W)) {
+        const int j5 = done512 * 512;
+        gpak_launch_diag_inverse(sf, j5, std::min(512, Np - j5), ctx->dM, ctx->ld, ctx->dInv,
+                                 ctx->dInv512 + (size_t)done512 * 512 * 512);
+        done512++;
+      }
     }
     const int J1 = J + W;
     if (J1 >= Np) break;

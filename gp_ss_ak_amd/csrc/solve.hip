@@ -203,9 +203,64 @@ __global__ __launch_bounds__(1024) void gpak_trsv_bwd_diag_f64(int J, int W, con
   }
 }
 
-// one block column [J, J+W), W <= 512.  scratch: 8 * 512 doubles
+// ---------------------------------------------------------------------------------------
+// Explicit inverse of a W x W (W <= 512) diagonal block, R = (L_bb^-1)^T, column-major with leading
+// dimension 512: forward substitution on an identity whose ROWS are the right-hand sides, 128 columns
+// at a time with the pre-inverted 128 x 128 blocks (same two products as every other panel step).
+// Seven tiny GEMM launches per block, issued on the side stream that carries the forward substitution,
+// i.e. hidden behind the factorisation.  It turns the diagonal step of the back substitution from four
+// dependent 128-column phases in one workgroup (46 us) into one matrix-vector product.
+// ---------------------------------------------------------------------------------------
+__global__ void gpak_identity_w_f64(double *R, int ld, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * ld) return;
+  const int c = i / ld, r = i - c * ld;
+  R[i] = (r == c) ? 1.0 : 0.0;
+}
+void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R) {
+  const int RL = BD_MAXW;
+  hipLaunchKernelGGL(gpak_identity_w_f64, dim3((W * RL + 255) / 256), dim3(256), 0, st, R, RL, W);
+  const int mt = W / SB;
+  for (int j0 = 0; j0 < W; j0 += SB) {
+    const double *ib = inv + (size_t)((J + j0) / SB) * 2 * SB * SB;
+    double *Rj = R + (size_t)j0 * RL;
+    gpak_launch_gemm_nt(st, mt, 1, SB, 1.0, Rj, RL, ib, SB, 0.0, Rj, RL, 0, 0, false, false);
+    const int nin = (W - j0 - SB) / SB;
+    if (nin > 0)
+      gpak_launch_gemm_nt(st, mt, nin, SB, -1.0, Rj, RL, L + (J + j0 + SB) + (size_t)(J + j0) * ld, ld, 1.0,
+                          R + (size_t)(j0 + SB) * RL, RL, 0, 0, false, false);
+  }
+}
+
+// part[cg][i] = sum_{c in column group cg} R[i, c] * v[c],  v = z_J - sum of the column-dot partials
+#define MV_CG 32
+__global__ __launch_bounds__(256) void gpak_bwd_diag_mv_f64(int J, int W, const double *__restrict__ R,
+                                                             const double *__restrict__ z,
+                                                             const double *__restrict__ spart, int nsplit,
+                                                             int spart_ld, double *__restrict__ part, int part_ld) {
+  __shared__ double v[MV_CG];
+  const int t = threadIdx.x, c0 = blockIdx.y * MV_CG;
+  if (t < MV_CG) {
+    double s = 0.0;
+    for (int r = 0; r < nsplit; r++) s += spart[(size_t)r * spart_ld + c0 + t];
+    v[t] = z[J + c0 + t] - s;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + t;
+  if (i >= W) return;
+  double x[MV_CG];
+#pragma unroll
+  for (int c = 0; c < MV_CG; c++) x[c] = R[i + (size_t)(c0 + c) * BD_MAXW];   // zero below the diagonal (i > c)
+  double a = 0.0;
+#pragma unroll
+  for (int c = 0; c < MV_CG; c++) a = fma(x[c], v[c], a);
+  part[(size_t)blockIdx.y * part_ld + i] = a;
+}
+
+// one block column [J, J+W), W <= 512.  scratch: (8 + 16) * 512 doubles.  Rinv: the block's explicit inverse
+// (gpak_launch_diag_inverse) or nullptr (then the four-phase single-workgroup kernel is used).
 void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const double *L, long ld, const double *inv,
-                                 const double *z, double *out, double *scratch) {
+                                 const double *z, double *out, double *scratch, const double *Rinv) {
   const int NB = BD_MAXW, rows = Np - (J + W);
   int R = 0, per = 0;
   if (rows > 0) {
@@ -215,17 +270,25 @@ void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const dou
     hipLaunchKernelGGL(gpak_coldot_split_f64, dim3(W / 4, R), dim3(256), 0, st, Np, J + W, J, W, per, L, ld, out, scratch,
                        NB);
   }
-  hipLaunchKernelGGL(gpak_trsv_bwd_diag_f64, dim3(1), dim3(1024), 0, st, J, W, L, ld, inv, z, scratch, R, NB, out);
+  if (Rinv) {
+    double *mvpart = scratch + 8 * NB;
+    hipLaunchKernelGGL(gpak_bwd_diag_mv_f64, dim3((W + 255) / 256, W / MV_CG), dim3(256), 0, st, J, W, Rinv, z, scratch, R,
+                       NB, mvpart, NB);
+    gpak_launch_sum_splits(st, mvpart, NB, W / MV_CG, W, out + J);
+  } else {
+    hipLaunchKernelGGL(gpak_trsv_bwd_diag_f64, dim3(1), dim3(1024), 0, st, J, W, L, ld, inv, z, scratch, R, NB, out);
+  }
 }
 
-// scratch: 8 * 512 doubles
+// scratch: 24 * 512 doubles.  Rinv512: explicit inverses of the 512-column diagonal blocks, 512 x 512 each, or nullptr
 void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
-                           double *out, double *scratch) {
+                           double *out, double *scratch, const double *Rinv512) {
   const int NB = BD_MAXW;
   const int nJ = (Np + NB - 1) / NB;
   for (int b = nJ - 1; b >= 0; b--) {
     const int J = b * NB, W = min(NB, Np - J);
-    gpak_launch_trsv_bwd_block2(st, Np, J, W, L, ld, inv, z, out, scratch);
+    gpak_launch_trsv_bwd_block2(st, Np, J, W, L, ld, inv, z, out, scratch,
+                                Rinv512 ? Rinv512 + (size_t)b * NB * NB : nullptr);
   }
 }
 

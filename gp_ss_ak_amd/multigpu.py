@@ -50,7 +50,7 @@ class HipEngine:
         for name in ("gpak_dev_transform", "gpak_dev_fill_b", "gpak_dev_factor_panel", "gpak_dev_update_block",
                      "gpak_dev_update_cyclic", "gpak_dev_trsv_fwd_block", "gpak_dev_coldot", "gpak_dev_trsv_bwd_block",
                      "gpak_dev_logdiag_block", "gpak_dev_kmatvec", "gpak_dev_nlz_terms", "gpak_dev_stream_create",
-                     "gpak_dev_stream_destroy", "gpak_dev_pack", "gpak_dev_trsv_bwd_packed"):
+                     "gpak_dev_stream_destroy", "gpak_dev_pack", "gpak_dev_trsv_bwd_packed", "gpak_dev_diag_inverse"):
             if not hasattr(self.lib, name):
                 raise RuntimeError(f"libgpak_hip.so lacks {name}")
             getattr(self.lib, name).restype = C.c_int
@@ -176,10 +176,15 @@ class HipEngine:
         self._chk(self.lib.gpak_dev_trsv_bwd_block(self._st(), self._pshift(blk, row0), C.c_long(ld), J, W,
                                                    self._p(inv), self._p(x), self._p(out)), "gpak_dev_trsv_bwd_block")
 
-    def trsv_bwd_packed(self, panel, ldp, row0, Np, J, W, inv, z, scratch, out):
+    def trsv_bwd_packed(self, panel, ldp, row0, Np, J, W, inv, z, scratch, out, rinv=None):
         self._chk(self.lib.gpak_dev_trsv_bwd_packed(self._st(), self._p(panel), C.c_long(ldp), int(row0), Np, J, W,
-                                                    self._p(inv), self._p(z), self._p(scratch), self._p(out)),
+                                                    self._p(inv), self._p(z), self._p(scratch), self._p(out),
+                                                    self._p(rinv) if rinv is not None else C.c_void_p(None)),
                   "gpak_dev_trsv_bwd_packed")
+
+    def diag_inverse(self, panel, ldp, row0, J, W, inv, rinv):
+        self._chk(self.lib.gpak_dev_diag_inverse(self._st(), self._p(panel), C.c_long(ldp), int(row0), J, W,
+                                                 self._p(inv), self._p(rinv)), "gpak_dev_diag_inverse")
 
     def logdiag_block(self, blk, ld, J, W, N, out):
         self._chk(self.lib.gpak_dev_logdiag_block(self._st(), self._p(blk), C.c_long(ld), J, W, N, self._p(out)),
@@ -237,6 +242,7 @@ class DistGP:
         self.params = None
         self.bytes_broadcast = 0
         self.panels, self.invs = {}, {}   # pipelined schedule: every rank keeps every packed panel + inverses
+        self.rinv, self.rinv_ok = {}, set()   # explicit inverses of the diagonal blocks (valid for the current factor)
         # sub-panel broadcasts pay off when there IS a transfer to hide; one rank keeps whole panels
         # (235.6 vs 231.0 ms at N=32768 on one GPU)
         self.pipeline = ((os.environ.get("GPAK_DIST_PIPELINE", "1") != "0" and self.P > 1) if pipeline is None
@@ -292,6 +298,7 @@ class DistGP:
         schedule) the forward substitution L^-1 rhs rides along: each rank applies panel b to its own copy right
         after its bulk update, in the slack the serial panel chain leaves on the main stream."""
         self._fwd = None
+        self.rinv_ok = set()
         if self.pipeline:
             if rhs is not None:
                 self._fwd = (rhs.clone(), self.eng.zeros(self.Np))
@@ -403,6 +410,17 @@ class DistGP:
         self.panels[b], self.invs[b] = buf, inv
         return buf, handles
 
+    def _diag_inverse(self, b, panel, rows):
+        """Explicit inverse of block column b's diagonal block (width <= 512), queued in the main stream's slack; the
+        back substitution then needs one matrix-vector product per block instead of four dependent phases."""
+        J, W = self.start(b), self.width(b)
+        if W > 512 or not hasattr(self.eng, "diag_inverse"):
+            return
+        if b not in self.rinv:
+            self.rinv[b] = self.eng.empty(512 * 512)
+        self.eng.diag_inverse(panel, rows, J, J, W, self.invs[b], self.rinv[b])
+        self.rinv_ok.add(b)
+
     def _factor_pipelined(self):
         """Column c receives panel b <= c-3 in the bulk update of step b (main stream), panel c-2 as one
         K=nb update and panel c-1 sub-panel by sub-panel (both on the side stream, in that order)."""
@@ -441,6 +459,7 @@ class DistGP:
             if nxt >= self.nJ:
                 if self._fwd is not None:
                     self.eng.trsv_fwd_block(panel, rows, self.Np, J, W, self.invs[b], self._fwd[0], self._fwd[1], row0=J)
+                    self._diag_inverse(b, panel, rows)
                 break
             panel_next, handles_next = None, []
             if streams:
@@ -456,6 +475,7 @@ class DistGP:
                                        self.rank, lb0, len(self.owned), self.width(self.owned[-1]))
             if self._fwd is not None:
                 self.eng.trsv_fwd_block(panel, rows, self.Np, J, W, self.invs[b], self._fwd[0], self._fwd[1], row0=J)
+                self._diag_inverse(b, panel, rows)
             panel, handles = panel_next, handles_next
         if streams:
             main.wait_stream(ps)
@@ -477,10 +497,11 @@ class DistGP:
                     J, W = self.start(b), self.width(b)
                     eng.trsv_fwd_block(self.panels[b], self.Np - J, self.Np, J, W, self.invs[b], xw, z, row0=J)
             x = eng.zeros(self.Np)
-            scratch = eng.empty(8 * 512)
+            scratch = eng.empty(24 * 512)
             for b in range(self.nJ - 1, -1, -1):
                 J, W = self.start(b), self.width(b)
-                eng.trsv_bwd_packed(self.panels[b], self.Np - J, J, self.Np, J, W, self.invs[b], z, scratch, x)
+                eng.trsv_bwd_packed(self.panels[b], self.Np - J, J, self.Np, J, W, self.invs[b], z, scratch, x,
+                                    rinv=self.rinv[b] if b in self.rinv_ok else None)
             return x
         xw = rhs.clone() if self.rank == 0 else eng.zeros(self.Np)
         z = eng.zeros(self.Np)

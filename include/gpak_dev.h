@@ -60,10 +60,16 @@ int gpak_dev_trsv_bwd_block(void *stream, const double *blk, long ld, int J, int
                             double *out);
 /* Back substitution step for block column [J, J+W) held as a PACKED panel (element 0 of each column = global row
  * row0, leading dimension ldp):  out[J..J+W) = L_bb^-T ( z[J..J+W) - sum_{r >= J+W} L[r, J..J+W) out[r] ).
- * z is read-only; scratch holds 8*512 doubles; W <= 512.  Two launches (streamed column dots + one workgroup
- * for the diagonal block). */
+ * z is read-only; scratch holds 24*512 doubles; W <= 512.  rinv: the explicit inverse of the diagonal block from
+ * gpak_dev_diag_inverse (then: streamed column dots + one matrix-vector product), or NULL (then one workgroup
+ * solves the diagonal block in four dependent 128-column phases). */
 int gpak_dev_trsv_bwd_packed(void *stream, const double *panel, long ldp, int row0, int Np, int J, int W,
-                             const double *inv, const double *z, double *scratch, double *out);
+                             const double *inv, const double *z, double *scratch, double *out, const double *rinv);
+/* rinv (512 x 512 doubles, leading dimension 512) <- (L_bb^-1)^T of the W x W diagonal block of a packed panel
+ * (row0 = global row of element 0 of each column).  Seven small launches; meant to be queued where the stream
+ * has slack (right after the panel arrives). */
+int gpak_dev_diag_inverse(void *stream, const double *panel, long ldp, int row0, int J, int W, const double *inv,
+                          double *rinv);
 /* out[0] = sum of log L[c,c] over the valid (c < N) columns of the block column */
 int gpak_dev_logdiag_block(void *stream, const double *blk, long ld, int J, int W, int N, double *out);
 

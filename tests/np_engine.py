@@ -129,7 +129,7 @@ class NumpyEngine:
             if k > 0:
                 xn[J:j0] -= M[j0:j0 + TILE, :k * TILE].T @ w
 
-    def trsv_bwd_packed(self, panel, ldp, row0, Np, J, W, inv, z, scratch, out):
+    def trsv_bwd_packed(self, panel, ldp, row0, Np, J, W, inv, z, scratch, out, rinv=None):
         s = torch.zeros(W, dtype=torch.float64)
         if J + W < Np:
             self.coldot(panel, ldp, Np, J, W, out, s, row0=row0)
