@@ -181,7 +181,7 @@ def run_single(args):
                             "algorithmic_flops": 2.0 * tim["n_padded"] ** 3 / 3.0,
                             "tflops": 2.0 * tim["n_padded"] ** 3 / 3.0 / (tg["grad_ms"] * 1e-3) / 1e12,
                             "g": [float(v) for v in gv]}
-    pmc = os.path.join(ROOT, "profiles", "r01_i_pmc_summary_N32768.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_j_pmc_summary_N32768.json")
     if N == 32768 and os.path.exists(pmc):
         # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes (separate runs of
         # this command): per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads
@@ -189,7 +189,7 @@ def run_single(args):
         k = "void gpak_gemm_nt_f64_rs<4, 2, true>"
         f, w = z["FETCH_SIZE"][k]["FETCH_SIZE"], z["WRITE_SIZE"][k]["WRITE_SIZE"]
         out["roofline"]["traffic"] = (2.0 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024.0
-        out["roofline"]["traffic_source"] = "profiles/r01_i_pmc_summary_N32768.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
+        out["roofline"]["traffic_source"] = "profiles/r01_j_pmc_summary_N32768.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
     if args.calibrate:
         tf, gbs = g.calibrate()
         out["roofline"]["calibrated_mfma_f64_tflops"] = tf
