@@ -138,6 +138,7 @@ void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, in
 // fixed order (deterministic).
 // ---------------------------------------------------------------------------------------
 #define KMV_CHUNK 256
+#define KMV_COLS 2   // target columns per thread: every LDS read of a source point serves two evaluations
 template <int NT>
 __global__ __launch_bounds__(256) void gpak_kmatvec_part_f64(const double *__restrict__ P, int capP, int nP, int p_off,
                                                               const double *__restrict__ w, int per_split,
@@ -147,18 +148,25 @@ __global__ __launch_bounds__(256) void gpak_kmatvec_part_f64(const double *__res
   constexpr int MT = NT ? NT : GPAK_MAX_TERMS;
   __shared__ double sp[MT * GPAK_PT + 1][KMV_CHUNK];
   const int nterms = NT ? NT : kp.nterms;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = j < nQ;
-  double b[MT][GPAK_PT];
+  int j[KMV_COLS];
+  bool ok[KMV_COLS];
+  double b[KMV_COLS][MT][GPAK_PT];
 #pragma unroll
-  for (int m = 0; m < MT; m++)
-    if (m < nterms) {
+  for (int q = 0; q < KMV_COLS; q++) {
+    j[q] = (blockIdx.x * KMV_COLS + q) * 256 + threadIdx.x;
+    ok[q] = j[q] < nQ;
 #pragma unroll
-      for (int c = 0; c < GPAK_PT; c++) b[m][c] = ok ? PARR(Q, capQ, m, c)[j] : 0.0;
-    }
+    for (int m = 0; m < MT; m++)
+      if (m < nterms) {
+#pragma unroll
+        for (int c = 0; c < GPAK_PT; c++) b[q][m][c] = ok[q] ? PARR(Q, capQ, m, c)[j[q]] : 0.0;
+      }
+  }
   const int i_begin = blockIdx.y * per_split;
   const int i_end = min(nP, i_begin + per_split);
-  double acc = 0.0;
+  double acc[KMV_COLS];
+#pragma unroll
+  for (int q = 0; q < KMV_COLS; q++) acc[q] = 0.0;
   for (int i0 = i_begin; i0 < i_end; i0 += KMV_CHUNK) {
     const int i = i0 + threadIdx.x;
     const bool v = i < i_end;
@@ -170,19 +178,27 @@ __global__ __launch_bounds__(256) void gpak_kmatvec_part_f64(const double *__res
     __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < KMV_CHUNK; k++) {
-      double kv = kp.bias;
+      double kv[KMV_COLS];
+#pragma unroll
+      for (int q = 0; q < KMV_COLS; q++) kv[q] = kp.bias;
 #pragma unroll
       for (int m = 0; m < MT; m++) {
         if (m >= nterms) break;
-        const double d2 = gpak_d2(sp[GPAK_PT * m][k], sp[GPAK_PT * m + 1][k], sp[GPAK_PT * m + 2][k],
-                                  sp[GPAK_PT * m + 3][k], sp[GPAK_PT * m + 4][k], b[m][0], b[m][1], b[m][2], b[m][3],
-                                  b[m][4], kp.mode);
-        kv += gpak_profile(d2, kp.term[m]);
+        const double p0 = sp[GPAK_PT * m][k], p1 = sp[GPAK_PT * m + 1][k], p2 = sp[GPAK_PT * m + 2][k],
+                     p3 = sp[GPAK_PT * m + 3][k], p4 = sp[GPAK_PT * m + 4][k];
+#pragma unroll
+        for (int q = 0; q < KMV_COLS; q++)
+          kv[q] += gpak_profile(gpak_d2(p0, p1, p2, p3, p4, b[q][m][0], b[q][m][1], b[q][m][2], b[q][m][3], b[q][m][4],
+                                        kp.mode), kp.term[m]);
       }
-      acc = fma(sp[MT * GPAK_PT][k], kv, acc);
+      const double wk = sp[MT * GPAK_PT][k];
+#pragma unroll
+      for (int q = 0; q < KMV_COLS; q++) acc[q] = fma(wk, kv[q], acc[q]);
     }
   }
-  if (ok) part[(size_t)blockIdx.y * part_ld + j] = acc;
+#pragma unroll
+  for (int q = 0; q < KMV_COLS; q++)
+    if (ok[q]) part[(size_t)blockIdx.y * part_ld + j[q]] = acc[q];
 }
 
 __global__ void gpak_kmatvec_reduce_f64(const double *__restrict__ part, int part_ld, int splits, int nQ,
@@ -201,7 +217,7 @@ void gpak_launch_sum_splits(hipStream_t st, const double *part, int part_ld, int
 
 // scratch must hold splits*Q.cap doubles; splits is chosen by the caller via gpak_kmatvec_splits
 int gpak_kmatvec_splits(int nP, int nQ) {
-  int wg = (nQ + 255) / 256;
+  int wg = (nQ + 256 * KMV_COLS - 1) / (256 * KMV_COLS);
   int s = 2048 / (wg > 0 ? wg : 1);
   if (s < 1) s = 1;
   if (s > 64) s = 64;
@@ -215,7 +231,7 @@ void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, int p_off, int np, 
                          const KernParams &kp, double *scratch, int splits, double *out) {
   int per = (np + splits - 1) / splits;
   per = (per + KMV_CHUNK - 1) / KMV_CHUNK * KMV_CHUNK;
-  dim3 grid((Q.n + 255) / 256, splits);
+  dim3 grid((Q.n + 256 * KMV_COLS - 1) / (256 * KMV_COLS), splits);
   if (kp.nterms == 1)
     hipLaunchKernelGGL(gpak_kmatvec_part_f64<1>, grid, dim3(256), 0, st, P.base, P.cap, np, p_off, w, per, Q.base,
                        Q.cap, Q.n, kp, scratch, Q.cap);
