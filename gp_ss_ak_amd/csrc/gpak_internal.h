@@ -146,7 +146,7 @@ __device__ __forceinline__ double gpak_sqrt_nonneg(double d) {
   g = fma(g, r, g);
   h = fma(h, r, h);
   g = fma(fma(-g, g, d), h, g);
-  return d > 0.0 ? g : 0.0;  // rsq(0) = inf
+  return d > 0.0 ? g : d;    // d == 0 (rsq(0) = inf) gives 0; a NaN coordinate stays NaN
 }
 // exp(x), x <= 0 finite: x = n ln2 + r, |r| <= 0.35, Taylor polynomial of degree 13 (remainder 4e-18), ldexp
 __device__ __forceinline__ double gpak_exp_nonpos(double x) {

@@ -302,6 +302,21 @@ def test_alternative_kernels_give_the_same_step():
         assert abs(v - vals["default"]) <= 1e-11 * abs(vals["default"]), (name, vals)
 
 
+def test_nan_input_is_not_hidden(gp):
+    """A NaN coordinate must surface (NaN entries in K, Chol_fail -> NaN nlZ as at GP_Utils.cpp:1145-1158), not be
+    turned into a finite number by the in-line sqrt/exp."""
+    X, y = synth.drillholes(200)
+    X = np.asfortranarray(X)
+    X[17, 1] = np.nan
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    K = gp.gram()
+    # (the pooled mean of MahaDist is NaN too, so like in the reference every entry is affected)
+    assert np.all(np.isnan(K[17, :])) and np.all(np.isnan(K[:, 17]))
+    assert math.isnan(gp.logLikelihood())
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+
+
 def test_options_and_two_live_contexts(orc):
     """gpak_set_option: every schedule variant gives the same numbers (look-ahead off = the classical order on
     one stream; other outer block sizes); value memoisation skips the rebuild only for bit-identical parameters;
