@@ -187,6 +187,97 @@ __global__ __launch_bounds__(256, 3) void gpak_gemm_nt_f32_rs(int K, float alpha
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same with a 128 x 64 wave tile (256 x 128 per workgroup): 3 operand loads per 32 MFMAs instead of
+// 4 -- the fp32 MFMA runs at twice the fp64 rate, so per clock this path asks the vector L1 / L2 for twice
+// the operand bytes of the fp64 kernel, and that, not instruction issue, is what holds it below its peak.
+// Needs an even number of 128-row tiles (the prediction batches are padded to 256 rows).
+// ---------------------------------------------------------------------------------------
+template <int RS_D>
+__global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f32_rs2(int K, float alpha, const float *A, long lda,
+                                                                const float *B, long ldb, float beta, float *C,
+                                                                long ldc, int mt2, int nt) {
+  int ti, tj;
+  {
+    const int b = blockIdx.x, q = b >> 3;
+    const int slot = q & 63;
+    const int ssel = (q >> 6) * 8 + (b & 7);
+    const int SR = (mt2 + 7) >> 3, SC = (nt + 7) >> 3;
+    const int sj = ssel / SR, si = ssel - sj * SR;
+    if (sj >= SC) return;
+    ti = si * 8 + (slot & 7);
+    tj = sj * 8 + (slot >> 3);
+    if (ti >= mt2 || tj >= nt) return;
+  }
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w & 1, wc = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const f4 *Ap = reinterpret_cast<const f4 *>(A + (size_t)ti * 256 + wr * 128 + 4 * l15 + (size_t)l4 * lda);
+  const f4 *Bp = reinterpret_cast<const f4 *>(B + (size_t)tj * TN + wc * 64 + 4 * l15 + (size_t)l4 * ldb);
+  const size_t sa = (size_t)lda, sb = (size_t)ldb;
+  f4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (f4){0.f, 0.f, 0.f, 0.f};
+  f4 ra[RS_D][2], rbv[RS_D];
+#define RS_LOAD(slot_)      \
+  ra[slot_][0] = Ap[0];     \
+  ra[slot_][1] = Ap[16];    \
+  rbv[slot_] = *Bp;         \
+  Ap += sa;                 \
+  Bp += sb;
+#define RS_MFMA(slot_)                                                                                      \
+  _Pragma("unroll") for (int mi = 0; mi < 8; mi++) _Pragma("unroll") for (int ni = 0; ni < 4; ni++)         \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(rbv[slot_][ni], ra[slot_][mi >> 2][mi & 3], acc[mi][ni], 0, 0, 0);
+  const int n = K / 4;
+#pragma unroll
+  for (int s = 0; s < RS_D; s++) { RS_LOAD(s) }
+  int g = 0;
+  for (; g + 2 * RS_D <= n; g += RS_D) {
+#pragma unroll
+    for (int s = 0; s < RS_D; s++) {
+      RS_MFMA(s)
+      RS_LOAD(s)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int r = n - (g + RS_D);
+#pragma unroll
+  for (int s = 0; s < RS_D; s++) {
+    RS_MFMA(s)
+    if (s < r) { RS_LOAD(s) }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 0; s < RS_D; s++)
+    if (s < r) { RS_MFMA(s) }
+#undef RS_LOAD
+#undef RS_MFMA
+  if (A == C) __syncthreads();
+  // of tile (mi, ni), register r4: C row 64 (mi >> 2) + 4 l15 + (mi & 3), C column 16 l4 + 4 r4 + ni
+  float *Cg = C + (size_t)ti * 256 + wr * 128 + 4 * l15 + ((size_t)tj * TN + wc * 64 + 16 * l4) * ldc;
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        f4 *p = reinterpret_cast<f4 *>(Cg + 64 * h + (size_t)(4 * r4 + ni) * ldc);
+        f4 v = {alpha * acc[4 * h][ni][r4], alpha * acc[4 * h + 1][ni][r4], alpha * acc[4 * h + 2][ni][r4],
+                alpha * acc[4 * h + 3][ni][r4]};
+        if (beta != 0.f) {
+          const f4 c = *p;
+          v.x = fmaf(beta, c.x, v.x);
+          v.y = fmaf(beta, c.y, v.y);
+          v.z = fmaf(beta, c.z, v.z);
+          v.w = fmaf(beta, c.w, v.w);
+        }
+        *p = v;
+      }
+}
+
 void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha, const float *A, long lda,
                              const float *B, long ldb, float beta, float *C, long ldc) {
   if (mt <= 0 || nt <= 0) return;
@@ -196,7 +287,11 @@ void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha,
   static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
   if (use_lds)
     hipLaunchKernelGGL(gpak_gemm_nt_f32, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
-  else
+  else if (!(mt & 1) && (!getenv("GPAK_F32_TILE") || atoi(getenv("GPAK_F32_TILE")) != 64)) {
+    const int mt2 = mt / 2, SR2 = (mt2 + 7) / 8;
+    dim3 grid2((unsigned)(((long)SR2 * SC + 7) / 8 * 8 * 64));
+    hipLaunchKernelGGL(gpak_gemm_nt_f32_rs2<4>, grid2, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt2, nt);
+  } else
     hipLaunchKernelGGL(gpak_gemm_nt_f32_rs<8>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
 }
 

@@ -154,10 +154,11 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   hipStream_t st = ctx->stream;
   const int N = ctx->N, Np = ctx->Np;
   int batch = 16384;  // measured at N=32768: 4096 -> 58 (f64) / 91 (f32) TFLOP/s, 16384 -> 70.5 / 100.5
-  if (const char *e = getenv("GPAK_PRED_BATCH")) batch = std::max(PB, atoi(e) / PB * PB);
+  if (const char *e = getenv("GPAK_PRED_BATCH")) batch = std::max(2 * PB, atoi(e) / (2 * PB) * (2 * PB));
   // keep the cross-kernel batch under ~8 GiB
-  while (batch > PB && (size_t)batch * Np * sizeof(double) > ((size_t)8 << 30)) batch /= 2;
-  long Mp = (M + PB - 1) / PB * PB;
+  while (batch > 2 * PB && (size_t)batch * Np * sizeof(double) > ((size_t)8 << 30)) batch /= 2;
+  batch = batch / (2 * PB) * (2 * PB);
+  long Mp = (M + 2 * PB - 1) / (2 * PB) * (2 * PB);   // 256-row granularity: the fp32 GEMM's workgroup tile
   const int cap = (int)std::min<long>(Mp, batch);
   int rc = ensure_predict_bufs(ctx, cap, var != nullptr);
   if (rc) return rc;
@@ -181,7 +182,7 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   std::vector<double> hsq;
   for (long b0 = 0; b0 < M; b0 += cap) {
     const int mb = (int)std::min<long>(cap, M - b0);
-    const int mbp = (mb + PB - 1) / PB * PB;
+    const int mbp = (mb + 2 * PB - 1) / (2 * PB) * (2 * PB);
     GPAK_HIP(hipMemsetAsync(ctx->dXte, 0, sizeof(double) * 4 * (size_t)cap, st));
     for (int k = 0; k < ctx->d; k++)
       GPAK_HIP(hipMemcpyAsync(ctx->dXte + (size_t)k * cap, Xte + (size_t)k * M + b0, sizeof(double) * mb,
