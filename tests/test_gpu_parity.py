@@ -398,14 +398,15 @@ def test_hip_path_matches_committed_golden_vectors(gp):
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
 
 
-def test_full_size_properties_n32768(gp):
-    """BASELINE.json's full size (N=32768, fp64): no CPU oracle finishes here in seconds, so the
+@pytest.mark.parametrize("N", [32768, 65536])
+def test_full_size_properties(gp, N):
+    """BASELINE.json's full sizes (N=32768: the metric; N=65536: configs[3], 34 GB on one GPU), fp64: no CPU
+    oracle finishes here in seconds, so the
     step is checked through identities that hold at any size:
       (K + sn2 I) alpha = y   =>   y - f = sn2 alpha  with f = K alpha computed by the device;
       quad = alpha'(f/2),  sumlp = -|y-f|^2/(2 sn2) - N/2 log(2 pi sn2);
       solve_chol is linear and inverts B = I + K/sn2 (checked on alpha itself);
       the step is deterministic (bit-identical when repeated)."""
-    N = 32768
     X, y = synth.drillholes(N)
     gp.set_train(X, y)
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
