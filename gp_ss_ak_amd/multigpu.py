@@ -88,9 +88,12 @@ class HipEngine:
         torch = _torch()
         if not hasattr(self, "_bulk"):
             h = C.c_void_p()
-            self._chk(self.lib.gpak_dev_stream_create(int(skip_cus), C.byref(h)), "gpak_dev_stream_create")
-            self._bulk_handle = h
-            self._bulk = torch.cuda.ExternalStream(h.value, device=self.device)
+            rc = self.lib.gpak_dev_stream_create(int(skip_cus), C.byref(h))
+            if rc == 0 and h.value:
+                self._bulk_handle = h
+                self._bulk = torch.cuda.ExternalStream(h.value, device=self.device)
+            else:   # CU masking unavailable (e.g. a partitioned device): an ordinary stream, only slower
+                self._bulk = torch.cuda.Stream(device=self.device)
         return self._bulk
 
     def _st(self):
