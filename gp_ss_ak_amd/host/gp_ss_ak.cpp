@@ -109,7 +109,8 @@ void GP_Cntrl::train() {
     std::cout << "Optimiser " << optimiser << " is not built on the HIP path; using LBFGS." << std::endl;
     GPModel->setOptimiser(GP_utils::LBFGS);
   } else ErrorTermination("Unrecognised optimiser type: " + optimiser);
-  GPModel->setMaxIters(iters);
+  // gp_ss_ak.cpp:295: the iteration count travels only through OptimisePars, which applies it when verbosity > 2
+  // (GP_Utils.cpp:1295-1296); otherwise the constructor's 100 (Opt_pars.h:35) stays.  Reproduced as written.
   GPModel->OptimisePars(iters);
 
   writeGPFile(*GPModel, modelName, "# GP_SS_AK Model File ");

@@ -22,6 +22,7 @@
 // NumPy restatement of the same source lines (tests/lbfgs_ref.py) on analytic objectives.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <limits>
@@ -364,6 +365,19 @@ static void Efficient_line_search(Opt_Algs *self, LbfgsState &st, const double f
   if (!returnflg) final_steplength = steplength;
 }
 
+// GPAK_OPT_TRACE=<file>: one line per iteration with the kept objective, the evaluation count so far and the
+// kept point at 17 significant digits (stdout carries 6, like the reference's `cout << fx`); test hook only.
+static void trace_iter(int iter, double fx, unsigned nfev, const Vec &x) {
+  const char *path = getenv("GPAK_OPT_TRACE");
+  if (!path) return;
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  fprintf(f, "%d %.17g %u", iter, fx, nfev);
+  for (double v : x) fprintf(f, " %.17g", v);
+  fprintf(f, "\n");
+  fclose(f);
+}
+
 // Opt_pars.cpp:179-332
 void Opt_Algs::LBFGSOptimise() {
   const int n = (int)getNumPars();
@@ -415,6 +429,7 @@ void Opt_Algs::LBFGSOptimise() {
     for (int i = 0; i < n; i++) { yk[i] = gnew[i] - gold[i]; sk[i] = Xnew[i] - Xold[i]; }
     if (dot(sk, yk) <= epsilon * dot(yk, yk)) {
       if (getVerbose() > 0) std::cout << "Iteration: " << iter << " -logL: " << fx << std::endl;
+      trace_iter(iter, fx, numFuncEval, X0);
       if (iter >= Maxit) break;
       continue;
     }
@@ -437,6 +452,7 @@ void Opt_Algs::LBFGSOptimise() {
       Mk = build_Mk(Dk, Sk, Yk, theta, mnc);
     }
     theta = dot(yk, yk) / dot(yk, sk);
+    trace_iter(iter, fx, numFuncEval, X0);
     if (iter >= Maxit) break;
     if (getVerbose() > 0) std::cout << "Iteration: " << iter << " -logL: " << fx << std::endl;
   }

@@ -1,0 +1,189 @@
+"""-m gpu: every BASELINE.json config at its stated size, and the shipped arithmetic (DIST_DIRECT) against the
+reference's arithmetic as written (expansion-form distance + IRLS/Brent sequence).
+
+  configs[1]  N=8192  fp64 Gram + Cholesky           -> oracle bound to OpenBLAS LAPACK + committed LAPACK golden
+  configs[2]  N=32768 fp64 (metric size)              -> committed LAPACK golden (tests/golden/golden_N32768.json)
+  configs[2]  gradient of the L-BFGS loop             -> oracle's as-written GradLL up to N=8192
+  configs[4]  N=32768 fp32 prediction                 -> GPAK_F32 context against the fp64 context, M=65536
+
+The golden JSON files are produced by tests/golden/make_golden_large.py (oracle Gram + SciPy/OpenBLAS
+cho_factor): they are NOT reference output (the reference cannot be built here: parity unpinned), but they come
+from neither the HIP path nor the oracle's own factorisation.  Observed differences are printed (pytest -s) and
+tabulated in DESIGN.md section 8.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from gp_ss_ak_amd import gpak, synth
+
+pytestmark = pytest.mark.gpu
+
+E = np.array(synth.DEFAULT_EXPANS)
+BIAS, SN2 = synth.DEFAULT_BIAS, synth.DEFAULT_SN2
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def golden(N):
+    with open(os.path.join(GOLD, f"golden_N{N}.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("N", [8192, 12288])
+def test_config2_factor_alpha_nlz_vs_lapack_oracle(gp, orc, N):
+    """configs[1] at its stated size (and 12288): the oracle's reference sequence with its Choleskys, triangular
+    solves and GEMVs issued to OpenBLAS (what Armadillo would call)."""
+    assert orc.use_lapack(16), "SciPy's OpenBLAS is part of the image"
+    try:
+        X, y = synth.drillholes(N)
+        gp.set_train(X, y)
+        gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        Ko = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+        info, alpha_o, Lo = orc.nlz_refseq(Ko, y, SN2)      # IRLS + Brent + 3 x dpotrf
+        assert gp.factor()
+        R = gp.chol_upper()
+        assert rel(R.T, Lo) <= 1e-11
+        del Lo
+        if N <= 8192:
+            Ko *= 1.0 / SN2
+            Ko[np.diag_indices(N)] += 1.0
+            assert rel(R.T @ R, Ko) <= 1e-13                # R'R = B
+        del R, Ko
+        assert rel(gp.solve_alpha(), alpha_o) <= 1e-8
+        nlz = gp.logLikelihood()
+        q, slp, ld = gp.nlz_terms()
+        print(f"\nN={N} HIP vs LAPACK-oracle: nlz {abs(nlz - info.nlz) / abs(info.nlz):.2e} "
+              f"logdet {abs(ld - info.logdet) / abs(info.logdet):.2e}")
+        assert abs(nlz - info.nlz) <= 1e-9 * abs(info.nlz)
+        assert abs(ld - info.logdet) <= 1e-11 * abs(info.logdet)
+        assert abs(q - info.quad) <= 1e-9 * abs(info.quad)
+        assert abs(slp - info.sumlp) <= 1e-9 * abs(info.sumlp)
+    finally:
+        orc.use_builtin()
+        gp.set_train(X[:64], y[:64])
+
+
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_config3_gradient_vs_oracle(gp, orc, N):
+    """The gradient every L-BFGS evaluation of configs[2] needs, against GradLL + getGradients as written
+    (GP_Utils.cpp:1171-1262, Kernel.cpp:886-1263) at configs[1]'s size."""
+    assert orc.use_lapack(16)
+    try:
+        X, y = synth.drillholes(N)
+        gp.set_train(X, y)
+        gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        g = gp.GradLL()
+        Ko = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+        info, alpha_o, Lo = orc.nlz_lean(Ko, y, SN2)
+        go = orc.grad_ref(X, y, Ko, Lo, alpha_o, E, BIAS, SN2, orc.DIST_DIRECT)
+        print(f"\nN={N} gradient: max |g - g_oracle| / max|g_oracle| = {np.abs(g - go).max() / np.abs(go).max():.2e}")
+        assert np.abs(g - go).max() <= 1e-8 * np.abs(go).max()
+    finally:
+        orc.use_builtin()
+        gp.set_train(X[:64], y[:64])
+
+
+@pytest.mark.parametrize("N", [512, 2048, 8192, 12288])
+def test_shipped_direct_vs_reference_expansion(gp, orc, N):
+    """The product default (DIST_DIRECT, one Cholesky + two trsv) against the reference's arithmetic AS WRITTEN:
+    expansion-form MahaDist with pooled-mean centring and clamp (Kernel.cpp:1391-1434) feeding the IRLS/Brent
+    sequence with three Choleskys (GP_Utils.cpp:191-381, 872-915, 1138-1162) and _postMean/_postVar
+    (:958-1004).  north_star's bound: 1e-5 relative on nlZ, predictive mean and variance."""
+    assert orc.use_lapack(16)
+    try:
+        X, y = synth.drillholes(N)
+        Xte = synth.test_points(64)
+        gp.set_train(X, y)
+        gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        nlz = gp.logLikelihood()
+        mean, var = gp.posteriorMeanVar(Xte)
+        Ko = orc.gram(X, X, E, BIAS, orc.DIST_EXPANSION)
+        info, alpha_o, Lo = orc.nlz_refseq(Ko, y, SN2)
+        mo, vo = orc.predict(X, Xte, E, BIAS, SN2, alpha_o, Lo, orc.DIST_EXPANSION, 0)
+        d = (abs(nlz - info.nlz) / abs(info.nlz), rel(mean, mo), rel(var, vo), rel(gp.solve_alpha(), alpha_o))
+        print(f"\nN={N} HIP-DIRECT vs oracle-EXPANSION-refseq: nlz {d[0]:.2e} mean {d[1]:.2e} var {d[2]:.2e} alpha {d[3]:.2e}")
+        assert d[0] <= 1e-5 and d[1] <= 1e-5 and d[2] <= 1e-5
+    finally:
+        orc.use_builtin()
+        gp.set_train(X[:64], y[:64])
+
+
+@pytest.mark.parametrize("N", [8192, 12288, 32768])
+def test_lapack_golden_scalars(gp, N):
+    """nlZ and its three terms, alpha samples and 16 predictions against the committed LAPACK-computed golden --
+    at the metric's own size too (N=32768 runs the 1024-wide panels of the `rows left > 20480` branch).
+    direct: the same formulation, 1e-9; expansion: the reference's formulation, north_star's 1e-5."""
+    z = golden(N)
+    X, y = synth.drillholes(N)
+    Xte = synth.test_points(16)
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    nlz = gp.logLikelihood()
+    q, slp, ld = gp.nlz_terms()
+    alpha = gp.solve_alpha()
+    mean, var = gp.posteriorMeanVar(Xte)
+    zd, ze = z["direct"], z["expansion"]
+    idx = np.array(z["alpha_idx"])
+    print(f"\nN={N} HIP vs LAPACK golden (direct): nlz {abs(nlz - zd['nlz']) / abs(zd['nlz']):.2e} "
+          f"logdet {abs(ld - zd['logdet']) / abs(zd['logdet']):.2e} quad {abs(q - zd['quad']) / abs(zd['quad']):.2e} "
+          f"sumlp {abs(slp - zd['sumlp']) / abs(zd['sumlp']):.2e} alpha {rel(alpha[idx], zd['alpha_samples']):.2e} "
+          f"mean {rel(mean, zd['mean']):.2e} var {rel(var, zd['var']):.2e}")
+    print(f"N={N} HIP-DIRECT vs LAPACK golden (expansion = reference arithmetic): "
+          f"nlz {abs(nlz - ze['nlz']) / abs(ze['nlz']):.2e} mean {rel(mean, ze['mean']):.2e} var {rel(var, ze['var']):.2e}")
+    assert abs(nlz - zd["nlz"]) <= 1e-9 * abs(zd["nlz"])
+    assert abs(ld - zd["logdet"]) <= 1e-10 * abs(zd["logdet"])
+    assert abs(q - zd["quad"]) <= 1e-9 * abs(zd["quad"])
+    assert abs(slp - zd["sumlp"]) <= 1e-9 * abs(zd["sumlp"])
+    assert rel(alpha[idx], zd["alpha_samples"]) <= 1e-8
+    assert abs(np.linalg.norm(alpha) - zd["alpha_norm"]) <= 1e-9 * zd["alpha_norm"]
+    assert rel(mean, zd["mean"]) <= 1e-8 and rel(var, zd["var"]) <= 1e-8
+    assert abs(nlz - ze["nlz"]) <= 1e-5 * abs(ze["nlz"])
+    assert rel(mean, ze["mean"]) <= 1e-5 and rel(var, ze["var"]) <= 1e-5
+    # the expansion mode of the HIP path itself, at the same bound
+    gp.set_params(E, BIAS, SN2, gpak.DIST_EXPANSION)
+    nlz_e = gp.logLikelihood()
+    me, ve = gp.posteriorMeanVar(Xte)
+    print(f"N={N} HIP-EXPANSION vs golden (expansion): nlz {abs(nlz_e - ze['nlz']) / abs(ze['nlz']):.2e} "
+          f"mean {rel(me, ze['mean']):.2e} var {rel(ve, ze['var']):.2e}")
+    assert abs(nlz_e - ze["nlz"]) <= 1e-5 * abs(ze["nlz"])
+    assert rel(me, ze["mean"]) <= 1e-5 and rel(ve, ze["var"]) <= 1e-5
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    gp.set_train(X[:64], y[:64])
+
+
+def test_config5_fp32_prediction_at_32768(gp):
+    """configs[4]: N=32768, fp32 prediction (GPAK_F32 context: fp64 training step, fp32 cross-kernel / forward
+    substitution / variance sums) against the fp64 context on M=65536 block-model points.
+    Tolerance: the latent variance kD - |L^-1 k*|^2/sn2 is a difference of two O(1) numbers computed through an
+    fp32 triangular solve with N=32768 terms per dot product: 1e-3 relative to the largest variance; the mean is
+    fp64 in both contexts (1e-9)."""
+    N, M = 32768, 65536
+    X, y = synth.drillholes(N)
+    Xte = synth.test_points(M)
+    g32 = gpak.Gpak(0, gpak.F32)
+    try:
+        gp.set_train(X, y)
+        gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        g32.set_train(X, y)
+        g32.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        assert g32.logLikelihood() == gp.logLikelihood()          # the training step is the same fp64 code
+        m64, v64 = gp.posteriorMeanVar(Xte)
+        m32, v32 = g32.posteriorMeanVar(Xte)
+        t64, t32 = gp.timing()["predict_ms"], g32.timing()["predict_ms"]
+        dv = np.abs(v32 - v64)
+        print(f"\nconfig5 N={N} M={M}: fp32 vs fp64 variance max rel {dv.max() / v64.max():.2e} "
+              f"(median {np.median(dv) / v64.max():.2e}), mean {rel(m32, m64):.2e}; "
+              f"predict fp64 {t64:.0f} ms, fp32 {t32:.0f} ms")
+        assert rel(m32, m64) <= 1e-9
+        assert dv.max() <= 1e-3 * v64.max()
+        assert np.all(v32 >= SN2 * (1 - 1e-6))
+    finally:
+        g32.close()
+        gp.set_train(X[:64], y[:64])

@@ -174,6 +174,54 @@ def test_cli_train_then_test_config1(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_lbfgs_trajectory_matches_oracle_driven_restatement(orc, tmp_path):
+    """f-2 on the real objective: `gp_ss_ak train` on configs[0]'s data (N=512) runs Opt_Algs::LBFGSOptimise over
+    the HIP path; tests/lbfgs_ref.py (the independent NumPy restatement of Opt_pars.cpp:179-332, 543-974) runs
+    over the ORACLE's reference sequence -- orc_nlz_refseq (IRLS/Brent, alpha warm-started from the previous
+    evaluation like the member `Alpha`, GP_Utils.cpp:191-228) + orc_grad_ref (GradLL + getGradients as written).
+    The kept objective after every iteration must agree to 1e-8 relative, the evaluation count exactly, the kept
+    point to 1e-7.  (stdout carries six digits, as the reference's `cout << fx` does; GPAK_OPT_TRACE is the
+    17-digit side channel.)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lbfgs_ref
+    build()
+    N, maxit = 512, 10
+    Xr, yr = synth.drillholes_raw(N)
+    write_csv(tmp_path / "train.txt", Xr, yr, sep="\t")
+    trace = tmp_path / "trace.txt"
+    env = dict(os.environ, GPAK_MAX_ITERS=str(maxit), GPAK_OPT_TRACE=str(trace))
+    out = subprocess.check_output([os.path.join(HOST, "gp_ss_ak"), "-v", "1", "-np", "train", "-k", "ExpAns", "-kn", "1",
+                                   "-o", "LBFGS", str(tmp_path / "train.txt"), str(tmp_path / "model")], env=env,
+                                  cwd=tmp_path).decode()
+    rows = [[float(v) for v in line.split()] for line in open(trace)]
+    printed = [float(line.split("-logL:")[1]) for line in out.splitlines() if line.startswith("Iteration:")]
+    # what the CLI sees: the text round trip at 17 digits is exact, then Control::prep_symmetric
+    Xs, ys, _ = synth.symmetric_standardise(Xr, yr)
+    state = {"alpha": None}
+
+    def fg(x):
+        e, bias, sn2 = np.array(x[:8], dtype=float), float(x[8]), float(x[9])
+        K = orc.gram(Xs, Xs, e, bias, orc.DIST_DIRECT)
+        info, alpha, L = orc.nlz_refseq(K, ys, sn2, alpha0=state["alpha"])
+        assert not info.chol_fail
+        state["alpha"] = alpha
+        return info.nlz, orc.grad_ref(Xs, ys, K, L, alpha, e, bias, sn2, orc.DIST_DIRECT)
+
+    x0 = list(E) + [synth.DEFAULT_BIAS, synth.DEFAULT_SN2]
+    xr, hist, nfev = lbfgs_ref.lbfgs_optimise(fg, x0, maxit)
+    assert len(rows) == len(hist) == maxit
+    for k, (row, h) in enumerate(zip(rows, hist)):
+        assert int(row[0]) == k + 1
+        assert abs(row[1] - h) <= 1e-8 * abs(h), (k, row[1], h)
+    assert int(rows[-1][2]) == nfev                               # same number of hot-path evaluations
+    assert np.abs(np.array(rows[-1][3:]) - xr).max() <= 1e-7
+    assert hist[-1] < hist[0] - 1.0                               # and the optimiser did move
+    for p, row in zip(printed, rows):                             # the stdout lines are the same numbers at 6 digits
+        assert abs(p - row[1]) <= 1e-5 * abs(row[1])
+
+
+@pytest.mark.gpu
 def test_class_surface_four_column_inputs(orc, tmp_path):
     """SURVEY Q7 through the C++ classes: x, y, z + rock type, InversewidthR_ExpAns in play, g[7] != 0."""
     build()
