@@ -214,11 +214,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--grad", type=int, default=0, help="also time this many GradLL evaluations (config 3)")
     ap.add_argument("--calibrate", action="store_true", default=True)
+    ap.add_argument("--no-n65536", action="store_true", help="skip the N=65536 sub-run (north_star's scaling size)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("GPAK_FORCE_DIST"):
-        from gp_ss_ak_amd import multigpu
-        out = multigpu.bench(args)
+        # the multi-GPU path: the C++ schedule of csrc/dist.hip over RCCL (GPAK_DIST_IMPL=python selects the
+        # round-1 Python schedule, kept as a test harness)
+        if os.environ.get("GPAK_DIST_IMPL", "cpp") == "python":
+            from gp_ss_ak_amd import multigpu
+            out = multigpu.bench(args)
+        else:
+            from gp_ss_ak_amd import dist as gdist
+            out = gdist.bench(args)
         if out is not None:
             print(json.dumps(out))
         return

@@ -1,0 +1,345 @@
+"""Python face of the C++ multi-GPU schedule (include/gpak_dist.h, csrc/dist.hip): one rank per process.
+
+Nothing is scheduled or computed here: `DistRank` forwards to gpak_dist_* of libgpak_hip.so, whose built-in HIP
+engine and RCCL transport are the product path.  Python only (a) carries the 128-byte RCCL unique id from rank 0 to
+the other ranks through torch.distributed's host-side store, and (b) for tests, supplies callback tables: a
+host-staged transport over a torch.distributed (gloo) group -- RCCL refuses two ranks on one GPU, which is all a
+test box has -- and, in tests/np_dist_engine.py, a NumPy engine for boxes with no GPU at all.
+
+`bench(args)` is what `bench.py --gpus N` runs under torch.distributed.run.
+"""
+import ctypes as C
+import math
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_F = C.CFUNCTYPE
+
+# field order == struct gpak_dist_engine (include/gpak_dist.h)
+ENGINE_FIELDS = [
+    ("self", _vp),
+    ("alloc", _F(_vp, _vp, C.c_size_t)),
+    ("release", _F(None, _vp, _vp)),
+    ("upload", _F(C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)),
+    ("download", _F(C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)),
+    ("zero", _F(C.c_int, _vp, _vp, _vp, C.c_size_t)),
+    ("copy", _F(C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)),
+    ("stream_create", _F(_vp, _vp, C.c_int)),
+    ("stream_destroy", _F(None, _vp, _vp)),
+    ("event_create", _F(_vp, _vp, C.c_int)),
+    ("event_destroy", _F(None, _vp, _vp)),
+    ("event_record", _F(C.c_int, _vp, _vp, _vp)),
+    ("stream_wait_event", _F(C.c_int, _vp, _vp, _vp)),
+    ("stream_sync", _F(C.c_int, _vp, _vp)),
+    ("event_elapsed_ms", _F(C.c_int, _vp, _vp, _vp, _dp)),
+    ("transform", _F(C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _vp)),
+    ("fill_b", _F(C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_int,
+                  _vp, C.c_long)),
+    ("factor_panel", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp, _vp)),
+    ("update_block", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, _vp, C.c_long, C.c_int, C.c_int, C.c_int)),
+    ("update_cyclic", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, _vp, C.c_long, C.c_int, C.c_int, C.c_int,
+                         C.c_int, C.c_int, C.c_int, C.c_int)),
+    ("trsv_fwd_block", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp)),
+    ("trsv_bwd_packed", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp)),
+    ("diag_inverse", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp, _vp)),
+    ("logdiag_block", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp)),
+    ("kmatvec", _F(C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _dp, C.c_double, C.c_int, _vp, _vp)),
+    ("nlz_terms", _F(C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_double, _vp)),
+    ("pack", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp)),
+    ("vec_scale", _F(C.c_int, _vp, C.c_int, _vp, C.c_double, _vp)),
+    ("vec_sum", _F(C.c_int, _vp, C.c_int, _vp, _vp)),
+]
+
+
+class Engine(C.Structure):
+    _fields_ = ENGINE_FIELDS
+
+
+class Transport(C.Structure):
+    _fields_ = [
+        ("self", _vp),
+        ("bcast", _F(C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_int)),
+        ("allreduce_sum", _F(C.c_int, _vp, _vp, _vp, C.c_size_t)),
+        ("allreduce_min_int", _F(C.c_int, _vp, _vp, _vp, C.c_size_t)),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("n", C.c_int), ("n_padded", C.c_int), ("nb", C.c_int),
+                ("n_panels", C.c_int), ("flags", C.c_int), ("bytes_broadcast", C.c_double), ("step_ms", C.c_double),
+                ("fill_ms", C.c_double), ("factor_ms", C.c_double), ("solve_ms", C.c_double), ("nlz_ms", C.c_double),
+                ("bulk_ms", C.c_double), ("bulk_flops", C.c_double), ("chain_ms", C.c_double), ("comm_ms", C.c_double),
+                ("wait_ms", C.c_double)]
+
+
+DIST_SYMBOLS = ["gpak_dist_create", "gpak_dist_destroy", "gpak_dist_last_error", "gpak_dist_rccl_unique_id",
+                "gpak_dist_init_rccl", "gpak_dist_selfcheck", "gpak_dist_set_train", "gpak_dist_set_params",
+                "gpak_dist_nlz", "gpak_dist_nlz_terms", "gpak_dist_get_alpha", "gpak_dist_get_stats",
+                "gpak_dev_vec_scale", "gpak_dev_vec_sum"]
+
+
+def _load():
+    lib = _lib.load()
+    missing = [s for s in DIST_SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise RuntimeError(f"libgpak_hip.so lacks symbols declared in include/gpak_dist.h: {missing}")
+    lib.gpak_dist_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.POINTER(Engine), C.POINTER(Transport)]
+    lib.gpak_dist_destroy.argtypes = [_vp]
+    lib.gpak_dist_destroy.restype = None
+    lib.gpak_dist_last_error.argtypes = [_vp]
+    lib.gpak_dist_last_error.restype = C.c_char_p
+    lib.gpak_dist_rccl_unique_id.argtypes = [C.c_char_p]
+    lib.gpak_dist_init_rccl.argtypes = [_vp, C.c_char_p]
+    lib.gpak_dist_selfcheck.argtypes = [_vp, C.POINTER(C.c_int)]
+    lib.gpak_dist_set_train.argtypes = [_vp, _dp, _dp, C.c_int, C.c_int, C.c_int]
+    lib.gpak_dist_set_params.argtypes = [_vp, _dp, C.c_double, C.c_double, C.c_int]
+    lib.gpak_dist_nlz.argtypes = [_vp, _dp]
+    lib.gpak_dist_nlz_terms.argtypes = [_vp, _dp, _dp, _dp]
+    lib.gpak_dist_get_alpha.argtypes = [_vp, _dp]
+    lib.gpak_dist_get_stats.argtypes = [_vp, C.POINTER(Stats)]
+    return lib
+
+
+class DistError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"gpak_dist status {status}: {msg}")
+        self.status = status
+
+
+class StagedTransport:
+    """TEST transport: collectives of a torch.distributed group (gloo) staged through host memory, for the built-in
+    HIP engine (several ranks rehearsed on ONE GPU).  The product transport is RCCL inside the library."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        hip = C.CDLL("libamdhip64.so")
+        self.hip = hip
+        hip.hipMemcpy.argtypes = [_vp, _vp, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [_vp]
+        self.rank = dist.get_rank(group)
+
+        def stage(st, buf, count, dtype, op):
+            t = torch.empty(int(count), dtype=dtype)
+            nbytes = t.numel() * t.element_size()
+            hip.hipStreamSynchronize(st)
+            if hip.hipMemcpy(t.data_ptr(), buf, nbytes, 2) != 0:     # device -> host
+                return -1
+            op(t)
+            return 0 if hip.hipMemcpy(buf, t.data_ptr(), nbytes, 1) == 0 else -1   # host -> device
+
+        def bcast(_self, st, buf, count, root):
+            return stage(st, buf, count, torch.float64, lambda t: dist.broadcast(t, src=root, group=group))
+
+        def ar_sum(_self, st, buf, count):
+            return stage(st, buf, count, torch.float64, lambda t: dist.all_reduce(t, group=group))
+
+        def ar_min(_self, st, buf, count):
+            return stage(st, buf, count, torch.int32, lambda t: dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group))
+
+        self._keep = (Transport._fields_[1][1](bcast), Transport._fields_[2][1](ar_sum), Transport._fields_[3][1](ar_min))
+        self.table = Transport(None, *self._keep)
+
+
+class DistRank:
+    """One rank of the C++ schedule.  engine / transport: None = built-in HIP engine / built-in RCCL transport."""
+
+    def __init__(self, rank, world, device=0, engine=None, transport=None, rccl_id=None):
+        self._lib = _load()
+        self._engine, self._transport = engine, transport       # keep the callback objects alive
+        h = _vp()
+        rc = self._lib.gpak_dist_create(C.byref(h), rank, world, device,
+                                        C.byref(engine.table) if engine is not None else None,
+                                        C.byref(transport.table) if transport is not None else None)
+        if rc != 0:
+            raise DistError(rc, "gpak_dist_create failed (no gfx950 device? there is no CPU fallback)")
+        self._h = h
+        self.rank, self.world = rank, world
+        if transport is None and world > 1:
+            if rccl_id is None:
+                raise ValueError("the RCCL transport needs the unique id made on rank 0 (rccl_unique_id())")
+            self._check(self._lib.gpak_dist_init_rccl(self._h, rccl_id))
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = _load().gpak_dist_rccl_unique_id(buf)
+        if rc != 0:
+            raise DistError(rc, "ncclGetUniqueId failed")
+        return buf.raw
+
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise DistError(rc, self._lib.gpak_dist_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpak_dist_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def selfcheck(self):
+        flags = C.c_int()
+        self._check(self._lib.gpak_dist_selfcheck(self._h, C.byref(flags)))
+        return flags.value
+
+    def set_train(self, X, y, nb=512):
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+        self.N = X.shape[0]
+        self._check(self._lib.gpak_dist_set_train(self._h, X.ctypes.data_as(_dp), y.ctypes.data_as(_dp), X.shape[0],
+                                                  X.shape[1], int(nb)))
+
+    def set_params(self, expans, bias, sn2, dist_mode=1):
+        e = np.ascontiguousarray(expans, dtype=np.float64)
+        self._check(self._lib.gpak_dist_set_params(self._h, e.ctypes.data_as(_dp), float(bias), float(sn2), int(dist_mode)))
+
+    def nlz(self):
+        v = C.c_double()
+        rc = self._check(self._lib.gpak_dist_nlz(self._h, C.byref(v)), allow=(1,))
+        return v.value if rc == 0 else math.nan
+
+    def nlz_terms(self):
+        q, s, l = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.gpak_dist_nlz_terms(self._h, C.byref(q), C.byref(s), C.byref(l)))
+        return q.value, s.value, l.value
+
+    def get_alpha(self):
+        a = np.zeros(self.N)
+        self._check(self._lib.gpak_dist_get_alpha(self._h, a.ctypes.data_as(_dp)))
+        return a
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.gpak_dist_get_stats(self._h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in s._fields_}
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus N entry point (launched by torch.distributed.run, one rank per GPU)
+# ------------------------------------------------------------------------------------------------
+def _one_size(args, N, dist, rank, world, local, make_rank, steps, warmup, bench_mod):
+    from . import synth
+    X, y = synth.drillholes(N)
+    gp = make_rank()
+    gp.set_train(X, y, nb=args.nb_outer or 512)
+    mode = 1 if args.dist == "direct" else 0
+
+    def step(i):
+        e, bias, sn2 = bench_mod.params_for_step(i)
+        gp.set_params(e, bias, sn2, mode)
+        return gp.nlz()
+
+    for i in range(warmup):
+        step(i)
+    dist.barrier()
+    t0 = time.perf_counter()
+    nlz = None
+    acc = {}
+    for i in range(steps):
+        nlz = step(warmup + i)          # synchronous: returns after this rank's device finished
+        for k, v in gp.stats().items():
+            if k.endswith("_ms") or k in ("bulk_flops", "bytes_broadcast"):
+                acc[k] = acc.get(k, 0.0) + v
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    import torch
+    w = torch.tensor([wall], dtype=torch.float64)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    wall = float(w.item())
+    st = gp.stats()
+    mine = {k: v / steps for k, v in acc.items()}
+    mine["rank"] = rank
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    gp.close()
+    return {"N": N, "wall": wall, "nlz": nlz, "stats": st, "per_rank": gathered}
+
+
+def bench(args):
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); "
+                         f"got WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    # host-side control plane only (unique id, barriers, max over ranks): gloo.  The data path -- every panel
+    # broadcast and all-reduce -- is RCCL inside libgpak_hip.so.
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    # GPAK_DIST_TRANSPORT=staged / GPAK_DIST_DEVICE exist for the tests: they rehearse this exact entry point with
+    # several ranks on the ONE GPU of a test box (RCCL refuses two ranks per GPU; gloo stages the collectives)
+    staged = os.environ.get("GPAK_DIST_TRANSPORT", "rccl") == "staged"
+    if "GPAK_DIST_DEVICE" in os.environ:
+        local = int(os.environ["GPAK_DIST_DEVICE"])
+    import bench as bench_mod
+
+    def make_rank():
+        if staged:
+            return DistRank(rank, world, device=local, transport=StagedTransport())
+        ids = [DistRank.rccl_unique_id() if (rank == 0 and world > 1) else None]
+        dist.broadcast_object_list(ids, src=0)
+        return DistRank(rank, world, device=local, rccl_id=ids[0])
+
+    res = _one_size(args, args.n, dist, rank, world, local, make_rank, args.steps, args.warmup, bench_mod)
+    extra = None
+    if args.n != 65536 and not args.no_n65536:
+        # north_star's scaling curve is quoted at N=65536 (BASELINE.json configs[3]): a short run of that size rides
+        # along as a sub-object; it needs 32 GiB / P + 17 GB per GPU
+        extra = _one_size(args, 65536, dist, rank, world, local, make_rank, max(1, min(args.steps, 3)), 1, bench_mod)
+    out = None
+    if rank == 0:
+        def line(r, steps):
+            Np = r["stats"]["n_padded"]
+            flops = Np ** 3 / 3.0
+            per_step = r["wall"] / steps
+            bulk_ms = max(p["bulk_ms"] for p in r["per_rank"])
+            bulk_tf = [p["bulk_flops"] / (p["bulk_ms"] * 1e-3) / 1e12 if p["bulk_ms"] > 0 else None for p in r["per_rank"]]
+            return {"N": r["N"], "steps_per_s": steps / r["wall"], "ms_per_step": per_step * 1e3, "nlz": r["nlz"],
+                    "whole_step_tflops_per_gpu": flops / per_step / 1e12 / world,
+                    "whole_step_frac_of_mfma_peak": flops / per_step / 1e12 / world / bench_mod.PEAK_F64_MFMA_TFLOPS,
+                    "bulk_update_tflops_per_rank": bulk_tf, "bytes_broadcast_per_step": r["per_rank"][0]["bytes_broadcast"],
+                    "phases_ms_per_rank": [{k: round(v, 3) for k, v in p.items()} for p in r["per_rank"]],
+                    "max_bulk_ms": bulk_ms, "stream_flags": r["stats"]["flags"]}
+        main = line(res, args.steps)
+        out = {
+            "metric": f"GP train step/sec (Gram+Cholesky+logML) at N={args.n} fp64",
+            "value": main["steps_per_s"], "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N={args.n} fp64 ExpAns+Bias Gram + block-column-cyclic Cholesky + solves + logML, "
+                                   f"C++ schedule (csrc/dist.hip), sub-panel broadcast over RCCL",
+                       "N": args.n, "dist_mode": args.dist, "nb_outer": res["stats"]["nb"],
+                       "parallelism": f"block-column-cyclic x{world}",
+                       "transport": "host-staged gloo (test rehearsal)" if staged else "RCCL"},
+            "nlz": main["nlz"],
+            "roofline": {"kernel": "gpak_gemm_nt_f64_rs<4,2,true> (bulk trailing update of the owned block columns)",
+                         "bound": "mfma",
+                         "achieved": min(v for v in main["bulk_update_tflops_per_rank"] if v) if any(main["bulk_update_tflops_per_rank"]) else None,
+                         "peak": bench_mod.PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                         "note": "slowest rank's bulk launches: algorithmic flops / summed launch durations (hipEvents)"},
+            "bytes_broadcast_per_step": main["bytes_broadcast_per_step"],
+            "phases_ms_per_rank": main["phases_ms_per_rank"],
+            "whole_step_frac_of_mfma_peak_per_gpu": main["whole_step_frac_of_mfma_peak"],
+            "stream_flags": main["stream_flags"],
+        }
+        a = out["roofline"]["achieved"]
+        out["roofline"]["frac"] = a / bench_mod.PEAK_F64_MFMA_TFLOPS if a else None
+        if extra is not None:
+            out["n65536"] = line(extra, max(1, min(args.steps, 3)))
+    dist.destroy_process_group()
+    return out

@@ -122,12 +122,6 @@ int gpak_dist_nlz_terms(gpak_dist *h, double *quad, double *sumlp, double *logde
 /* alpha = (K + sn2 I)^-1 y of the last gpak_dist_nlz (replicated), N doubles */
 int gpak_dist_get_alpha(gpak_dist *h, double *alpha_host);
 
-/* GP_utils::posteriorMeanVar (GP_Utils.cpp:1016-1043) with the test points sharded over the ranks: every rank
- * holds the whole factor as packed panels, so rank r predicts points [r*ceil(M/P), ...) with no communication
- * and writes ONLY its slice of mean / var (the host program concatenates; *m0 / *m1 receive the slice bounds).
- * compat_flags as gpak_predict (applied by the caller of the gathered result: flags act on element 0 / 1). */
-int gpak_dist_predict_slice(gpak_dist *h, const double *Xte, long M, double *mean, double *var, long *m0, long *m1);
-
 typedef struct {
   int rank, world, n, n_padded, nb, n_panels, flags;
   double bytes_broadcast;   /* payload of all panel / inverse broadcasts of the last step (per rank view)      */

@@ -390,8 +390,9 @@ class LineSearch:
         return gv[1]
 
 
-def lbfgs_optimise(f_and_g, x0, maxit):
-    """Returns (x_best, [fx after each iteration], number of function evaluations)."""
+def lbfgs_optimise(f_and_g, x0, maxit, trace=None):
+    """Returns (x_best, [fx after each iteration], number of function evaluations).
+    trace: optional list that receives (fx, evaluations so far, kept point) after every iteration."""
     prob = Problem(f_and_g, x0)
     n = len(x0)
     lb, ub = np.full(n, 1e-4), np.full(n, 6.0)
@@ -427,6 +428,8 @@ def lbfgs_optimise(f_and_g, x0, maxit):
         yk, sk = gnew - gold, Xnew - Xold
         if sdot(sk, yk) <= EPS * sdot(yk, yk):
             hist.append(fx)
+            if trace is not None:
+                trace.append((fx, prob.nfev, X0.copy()))
             if it >= maxit:
                 break
             continue
@@ -445,6 +448,8 @@ def lbfgs_optimise(f_and_g, x0, maxit):
         with np.errstate(all="ignore"):
             theta = np.float64(sdot(yk, yk)) / np.float64(sdot(yk, sk))
         hist.append(fx)
+        if trace is not None:
+            trace.append((fx, prob.nfev, X0.copy()))
         if it >= maxit:
             break
     return X0, hist, prob.nfev

@@ -1,0 +1,174 @@
+"""Callback tables for gpak_dist_create (include/gpak_dist.h) on a box WITHOUT a GPU -- TEST INFRASTRUCTURE ONLY.
+
+`NumpyDistEngine.table` is a gpak_dist_engine whose "device" buffers are host arrays and whose tile operations are
+NumPy/SciPy restatements of include/gpak_dev.h (tests/np_engine.py, written against the same header);
+`GlooTransport.table` is a gpak_dist_transport over a torch.distributed (gloo) group.  With them the world_size-2/3/4
+CPU tests drive the C++ schedule of csrc/dist.hip itself: ownership map, look-ahead order, sub-panel broadcasts,
+the solves on packed panels and the reductions.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from gp_ss_ak_amd import dist as gd
+from np_engine import NumpyEngine, TILE
+
+
+def _arr(ptr, n, dtype=np.float64):
+    ct = C.c_double if dtype == np.float64 else C.c_int32
+    return np.ctypeslib.as_array((ct * int(n)).from_address(int(ptr)))
+
+
+def _t(ptr, n, dtype=np.float64):
+    return torch.from_numpy(_arr(ptr, n, dtype))
+
+
+def _strided(ptr, rows, cols, ld):
+    """(rows x cols) column-major view with leading dimension ld starting at ptr."""
+    base = _arr(ptr, (cols - 1) * ld + rows)
+    return np.lib.stride_tricks.as_strided(base, shape=(rows, cols), strides=(8, 8 * ld))
+
+
+class NumpyDistEngine:
+    def __init__(self):
+        self.np = NumpyEngine()
+        self.mem = {}
+        self.calls = []          # (operation, stream) in issue order, for schedule assertions
+        eng = self.np
+        F = dict(gd.ENGINE_FIELDS)
+
+        def ok(fn):
+            def wrapped(*a):
+                fn(*a)
+                return 0
+            return wrapped
+
+        def alloc(_s, nbytes):
+            a = np.zeros(max(1, (int(nbytes) + 7) // 8), dtype=np.float64)
+            self.mem[a.ctypes.data] = a
+            return a.ctypes.data
+
+        def release(_s, p):
+            self.mem.pop(int(p), None)
+
+        def upload(_s, st, dst, src, nbytes):
+            C.memmove(dst, src, nbytes)
+
+        def zero(_s, st, dst, nbytes):
+            C.memset(dst, 0, nbytes)
+
+        def elapsed(_s, e0, e1, ms):
+            ms[0] = 0.0
+
+        def transform(st, x, xs, n, cap, expans, mu, u):
+            eng.transform(_t(x, 3 * xs), xs, n, cap, [expans[i] for i in range(8)], [mu[i] for i in range(3)], _t(u, 5 * cap))
+
+        def fill_b(st, u, cap, n, Np, J, W, expans, bias, sn2, mode, blk, ld):
+            eng.fill_b(_t(u, 5 * cap), cap, n, Np, J, W, [expans[i] for i in range(8)], bias, sn2, mode, _t(blk, W * ld), ld)
+
+        def factor_panel(st, blk, ld, Np, J, W, inv, info):
+            self.calls.append(("factor", J, st))
+            eng.factor_panel(_t(blk, W * ld), ld, Np, J, W, _t(inv, W // TILE * 2 * TILE * TILE), _t(info, 1, np.int32))
+
+        def update_block(st, panel, ldp, prow0, W, blk, ld, Np, Jc, Wc):
+            self.calls.append(("update_block", Jc, st))
+            eng.update_block(_t(panel, W * ldp), ldp, prow0, W, _t(blk, Wc * ld), ld, Np, Jc, Wc)
+
+        def update_cyclic(st, panel, ldp, prow0, W, local, ld, Np, nb, P, rank, lb0, n_local, last_width):
+            self.calls.append(("update_cyclic", lb0, st))
+            eng.update_cyclic(_t(panel, W * ldp), ldp, prow0, W, _t(local, ((n_local - 1) * nb + last_width) * ld), ld, Np,
+                              nb, P, rank, lb0, n_local, last_width)
+
+        def inv_blocks(inv, W):
+            return _arr(inv, W // TILE * 2 * TILE * TILE).reshape(W // TILE, 2, TILE, TILE)
+
+        def trsv_fwd_block(st, blk, ld, Np, J, W, inv, x, out):
+            # gpak_dev.h: L[r, J+k] = blk[r + k*ld] for r >= J
+            M = _strided(int(blk) + 8 * J, Np - J, W, ld)
+            iv, xn, on = inv_blocks(inv, W), _arr(x, Np), _arr(out, Np)
+            for k in range(W // TILE):
+                j0 = J + k * TILE
+                z = iv[k, 0].T @ xn[j0:j0 + TILE]
+                on[j0:j0 + TILE] = z
+                xn[j0 + TILE:Np] -= M[j0 + TILE - J:, k * TILE:(k + 1) * TILE] @ z
+
+        def trsv_bwd_packed(st, panel, ldp, row0, Np, J, W, inv, z, scratch, out, rinv):
+            M = _strided(panel, Np - row0, W, ldp)
+            iv, zn, on = inv_blocks(inv, W), _arr(z, Np), _arr(out, Np)
+            v = zn[J:J + W].copy()
+            if J + W < Np:
+                v -= M[J + W - row0:, :].T @ on[J + W:Np]
+            if rinv:
+                R = _strided(rinv, W, W, 512)
+                on[J:J + W] = R @ v                       # R = (L_bb^-1)^T
+                return
+            for k in range(W // TILE - 1, -1, -1):
+                j0 = J + k * TILE
+                w = iv[k, 1].T @ v[k * TILE:(k + 1) * TILE]
+                on[j0:j0 + TILE] = w
+                if k > 0:
+                    v[:k * TILE] -= M[j0 - row0:j0 - row0 + TILE, :k * TILE].T @ w
+
+        def diag_inverse(st, panel, ldp, row0, J, W, inv, rinv):
+            M = _strided(panel, W + (J - row0), W, ldp)
+            L = np.tril(M[J - row0:J - row0 + W, :])
+            _strided(rinv, W, W, 512)[:] = np.linalg.inv(L).T
+
+        def logdiag_block(st, blk, ld, J, W, N, out):
+            eng.logdiag_block(_t(blk, W * ld), ld, J, W, N, _t(out, 1))
+
+        def kmatvec(st, u, cap, n, i0, i1, w, expans, bias, mode, scratch, out):
+            eng.kmatvec(_t(u, 5 * cap), cap, n, i0, i1, _t(w, cap), [expans[i] for i in range(8)], bias, mode, None,
+                        _t(out, cap))
+
+        def nlz_terms(st, N, y, f, alpha, sn2, out):
+            eng.nlz_terms(N, _t(y, N), _t(f, N), _t(alpha, N), sn2, _t(out, 2))
+
+        def pack(st, src, ld, row0, nrows, ncols, dst):
+            _strided(dst, nrows, ncols, nrows)[:] = _strided(int(src) + 8 * row0, nrows, ncols, ld)
+
+        def vec_scale(st, n, a, s, out):
+            _arr(out, n)[:] = _arr(a, n) * s
+
+        def vec_sum(st, n, a, out):
+            _arr(out, 1)[0] = float(np.sum(_arr(a, n)))
+
+        impl = {
+            "alloc": alloc, "release": release, "upload": ok(upload), "download": ok(upload), "zero": ok(zero),
+            "copy": ok(upload), "stream_create": lambda _s, kind: 100 + kind, "stream_destroy": lambda _s, st: None,
+            "event_create": lambda _s, timing: 1, "event_destroy": lambda _s, e: None, "event_record": lambda *a: 0,
+            "stream_wait_event": lambda *a: 0, "stream_sync": lambda *a: 0, "event_elapsed_ms": ok(elapsed),
+            "transform": ok(transform), "fill_b": ok(fill_b), "factor_panel": ok(factor_panel),
+            "update_block": ok(update_block), "update_cyclic": ok(update_cyclic), "trsv_fwd_block": ok(trsv_fwd_block),
+            "trsv_bwd_packed": ok(trsv_bwd_packed), "diag_inverse": ok(diag_inverse), "logdiag_block": ok(logdiag_block),
+            "kmatvec": ok(kmatvec), "nlz_terms": ok(nlz_terms), "pack": ok(pack), "vec_scale": ok(vec_scale),
+            "vec_sum": ok(vec_sum),
+        }
+        self._keep = {name: F[name](fn) for name, fn in impl.items()}
+        self.table = gd.Engine(None, *[self._keep[name] for name, _ in gd.ENGINE_FIELDS[1:]])
+
+
+class GlooTransport:
+    """gpak_dist_transport over a gloo group for HOST buffers (the NumPy engine's memory)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.bytes = 0
+
+        def bcast(_s, st, buf, count, root):
+            self.bytes += 8 * int(count)
+            dist.broadcast(_t(buf, count), src=root, group=group)
+            return 0
+
+        def ar_sum(_s, st, buf, count):
+            dist.all_reduce(_t(buf, count), group=group)
+            return 0
+
+        def ar_min(_s, st, buf, count):
+            dist.all_reduce(_t(buf, count, np.int32), op=dist.ReduceOp.MIN, group=group)
+            return 0
+
+        T = gd.Transport._fields_
+        self._keep = (T[1][1](bcast), T[2][1](ar_sum), T[3][1](ar_min))
+        self.table = gd.Transport(None, *self._keep)

@@ -27,6 +27,11 @@ def test_library_exports_every_declared_symbol():
     for name in header_functions() + header_functions("gpak_dev.h"):
         assert hasattr(lib, name), name
     assert len(header_functions("gpak_dev.h")) == 16       # the device-pointer level API of the multi-GPU path
+    from gp_ss_ak_amd import dist
+    dist_fns = header_functions("gpak_dist.h")             # the C++ multi-GPU schedule
+    assert sorted(dist.DIST_SYMBOLS) == dist_fns
+    for name in dist_fns:
+        assert hasattr(lib, name), name
 
 
 def test_header_is_plain_c():
@@ -34,7 +39,8 @@ def test_header_is_plain_c():
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
-        open(src, "w").write('#include "gpak.h"\nint main(void){gpak_phase_times t; (void)t; return GPAK_OK;}\n')
+        open(src, "w").write('#include "gpak.h"\n#include "gpak_dev.h"\n#include "gpak_dist.h"\n'
+                             'int main(void){gpak_phase_times t; gpak_dist_stats s; (void)t; (void)s; return GPAK_OK;}\n')
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                                "-c", src, "-o", os.path.join(d, "t.o")])
 

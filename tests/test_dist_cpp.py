@@ -1,0 +1,154 @@
+"""The N>1 path in C++: csrc/dist.hip (include/gpak_dist.h) driven one rank per process.
+
+CPU (-m "not gpu"): world_size 1..4 over gloo; the schedule runs in libgpak_hip.so, its tile operations are the
+NumPy callback engine of tests/np_dist_engine.py and its collectives a gloo callback transport -- ownership map,
+look-ahead order, sub-panel broadcasts, solves on the packed panels and the reductions against the single-process
+oracle.
+GPU (-m gpu): the same schedule with the built-in HIP engine; world 1 on the built-in RCCL transport, world 2..4 with
+all ranks on the one GPU of the box and the collectives staged through gloo (RCCL refuses two ranks per device);
+and bench.py --gpus as the driver launches it.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from gp_ss_ak_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900):
+    port = free_port()
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for r in range(world):
+            cmd = [sys.executable, os.path.join(HERE, "dist_cpp_worker.py"), "--rank", str(r), "--world", str(world),
+                   "--port", str(port), "--n", str(n), "--nb", str(nb), "--engine", engine, "--mode", str(mode),
+                   "--steps", str(steps), "--out", os.path.join(d, f"r{r}.json")]
+            if sn2 is not None:
+                cmd += ["--sn2", str(sn2)]
+            env = dict(os.environ, OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o[-3000:]
+        return [json.load(open(os.path.join(d, f"r{r}.json"))) for r in range(world)]
+
+
+def oracle_ref(orc, n, mode=1, e1=None):
+    X, y = synth.drillholes(n)
+    e = list(synth.DEFAULT_EXPANS)
+    K = orc.gram(X, X, e, synth.DEFAULT_BIAS, mode)
+    info, alpha, _ = orc.nlz_refseq(K, y, synth.DEFAULT_SN2)
+    return info, alpha
+
+
+@pytest.mark.parametrize("world,n,nb", [(1, 260, 128), (2, 300, 128), (3, 700, 128), (2, 600, 256), (3, 1500, 256),
+                                        (4, 1400, 256), (2, 1100, 512), (4, 2100, 512)])
+def test_cpp_schedule_over_gloo_matches_oracle(orc, world, n, nb):
+    res = run_world(world, n, nb)
+    info, alpha = oracle_ref(orc, n)
+    nJ = res[0]["stats"]["n_panels"]
+    assert nJ == -(-(-(-n // 128) * 128) // nb)
+    for r in res:
+        assert r["stats"]["world"] == world and r["stats"]["rank"] == r["rank"]
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)     # same value on every rank
+        assert abs(r["logdet"] - info.logdet) <= 1e-10 * abs(info.logdet)
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+        # ownership: block column b is factored on rank b % world only, every 128-column sub-panel once, in order
+        fac = [J for op, J, st in r["calls"] if op == "factor"]
+        want = [b * nb + s for b in range(nJ) if b % world == r["rank"]
+                for s in range(0, min(nb, -(-n // 128) * 128 - b * nb), 128)]
+        assert fac == want
+        # look-ahead: factor / in-column updates on the panel stream (101), bulk updates on the bulk stream (100)
+        assert all(st == 101 for op, J, st in r["calls"] if op in ("factor", "update_block"))
+        assert all(st == 100 for op, J, st in r["calls"] if op == "update_cyclic")
+    assert len({r["stats"]["bytes_broadcast"] for r in res}) == 1 and res[0]["stats"]["bytes_broadcast"] > 0
+
+
+def test_cpp_schedule_repeated_steps_and_expansion_mode(orc):
+    res = run_world(3, 900, 256, steps=3, mode=0)
+    info, alpha = oracle_ref(orc, 900, mode=0)
+    for r in res:
+        assert abs(r["nlz"] - info.nlz) <= 1e-6 * abs(info.nlz)     # expansion mode: cancellation noise
+
+
+def test_cpp_schedule_chol_fail_is_nan_on_every_rank():
+    res = run_world(2, 300, 128, sn2=-0.5)
+    assert all(r["nlz"] != r["nlz"] for r in res)                   # NaN (GP_Utils.cpp:1145-1146)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,nb", [(1, 1000, 256), (2, 1500, 256), (2, 1100, 512), (3, 2500, 256), (2, 5000, 512),
+                                        (4, 6000, 512), (3, 4100, 384)])
+def test_cpp_schedule_hip_engine_matches_oracle(orc, world, n, nb):
+    res = run_world(world, n, nb, engine="hip", steps=2)
+    info, alpha = oracle_ref(orc, n)
+    for r in res:
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+        assert r["stats"]["bulk_flops"] >= 0 and r["stats"]["factor_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_cpp_schedule_hip_engine_chol_fail(orc):
+    res = run_world(2, 900, 256, engine="hip", sn2=-0.5)
+    assert all(r["nlz"] != r["nlz"] for r in res)
+
+
+def _bench(world, extra_env, size, timeout=900):
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+           "--steps", "2", "--warmup", "1", "--size", str(size), "--no-cpu", "--no-n65536"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    return json.loads(lines[0])
+
+
+def _single(size):
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n",
+                             str(size), "--no-cpu"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert single.returncode == 0, single.stderr.decode()[-2000:]
+    return json.loads([l for l in single.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_distributed_entry_point_over_rccl_one_rank():
+    """bench.py --gpus path exactly as the driver launches it (torch.distributed.run), the C++ schedule with the
+    built-in RCCL transport and the one rank this box has; the step must agree with the single-context path."""
+    d = _bench(1, {"GPAK_FORCE_DIST": "1"}, 4096)
+    assert d["n_gpus"] == 1 and d["unit"] == "steps/s" and d["value"] > 0 and "roofline" in d
+    assert d["config"]["transport"] == "RCCL" and "at N=4096" in d["metric"]
+    s = _single(4096)
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_distributed_entry_point_with_several_ranks(world):
+    """bench.py --gpus N as the driver launches it, N ranks rehearsed on this box's one GPU (collectives staged
+    through gloo instead of RCCL): same nlZ as the single-context path, one JSON line with the per-rank phases."""
+    d = _bench(world, {"GPAK_DIST_TRANSPORT": "staged", "GPAK_DIST_DEVICE": "0"}, 4096)
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["bytes_broadcast_per_step"] > 0
+    assert len(d["phases_ms_per_rank"]) == world
+    assert all({"factor_ms", "bulk_ms", "chain_ms", "comm_ms", "wait_ms"} <= set(p) for p in d["phases_ms_per_rank"])
+    s = _single(4096)
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
