@@ -593,7 +593,7 @@ int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out) {
 int gpak_calibrate(gpak_ctx *ctx, double *mfma_f64_tflops, double *hbm_write_gbs) {
   if (!ctx || !mfma_f64_tflops || !hbm_write_gbs) return GPAK_EINVAL;
   GPAK_HIP(hipSetDevice(ctx->device));
-  const size_t bytes = (size_t)1 << 30;
+  const size_t bytes = (size_t)4 << 30;
   double *scratch = nullptr;
   if (hipMalloc(&scratch, bytes) != hipSuccess) { ctx->err = "calibration scratch allocation failed"; return GPAK_ENOMEM; }
   int rc = gpak_calibrate_impl(ctx, scratch, bytes, mfma_f64_tflops, hbm_write_gbs);

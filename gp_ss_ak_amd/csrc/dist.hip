@@ -8,7 +8,10 @@
 //                   that the serial panel chain never queues behind the update's workgroups;
 //   panel (kind 1)  high priority: factor a block column 128 columns at a time, in-column updates, packs, and
 //                   the updates that bring the NEXT two block columns up to date (look-ahead);
-//   comm  (kind 2)  every collective of the factorisation, in one global order (b, sub-panel) on all ranks.
+//   comm  (kind 2)  every collective of the factorisation, in one global order (b, sub-panel) on all ranks;
+//   aux   (kind 3)  the forward substitution of y/sn2 and the explicit inverses of the diagonal blocks, which ride
+//                   along panel by panel (off the bulk stream: 11 short launches per panel would sit between two
+//                   bulk updates otherwise).
 //
 // Column c receives panel b <= c-3 in the bulk update of step b (bulk stream), panel c-2 as one K=nb update and
 // panel c-1 sub-panel by sub-panel as the broadcasts land (panel stream, in that order): no two streams ever
@@ -211,7 +214,7 @@ struct gpak_dist {
   std::string err;
 
   // streams
-  void *s_bulk = nullptr, *s_panel = nullptr, *s_comm = nullptr;
+  void *s_bulk = nullptr, *s_panel = nullptr, *s_comm = nullptr, *s_aux = nullptr;
   bool own_comm_stream = false;
   int flags = 0;
   bool checked = false;
@@ -306,6 +309,7 @@ static int ensure_streams(gpak_dist *h) {
   }
   h->s_bulk = E.stream_create(E.self, 0);
   h->s_panel = E.stream_create(E.self, 1);
+  h->s_aux = E.stream_create(E.self, 3);
   if (h->builtin_engine && h->hip_state.mask_failed) h->flags |= GPAK_DIST_FLAG_CU_MASK_OFF;
   if (h->flags & GPAK_DIST_FLAG_COMM_INLINE) {
     h->s_comm = h->s_panel;
@@ -314,7 +318,7 @@ static int ensure_streams(gpak_dist *h) {
     h->s_comm = E.stream_create(E.self, 2);
     h->own_comm_stream = true;
   }
-  if ((!h->s_bulk || !h->s_panel || !h->s_comm) && h->builtin_engine) { h->err = "stream creation failed"; return GPAK_EHIP; }
+  if ((!h->s_bulk || !h->s_panel || !h->s_comm || !h->s_aux) && h->builtin_engine) { h->err = "stream creation failed"; return GPAK_EHIP; }
   return GPAK_OK;
 }
 
@@ -322,8 +326,9 @@ static void drop_streams(gpak_dist *h) {
   gpak_dist_engine &E = h->E;
   if (h->own_comm_stream && h->s_comm) E.stream_destroy(E.self, h->s_comm);
   if (h->s_panel) E.stream_destroy(E.self, h->s_panel);
+  if (h->s_aux) E.stream_destroy(E.self, h->s_aux);
   if (h->s_bulk) E.stream_destroy(E.self, h->s_bulk);
-  h->s_bulk = h->s_panel = h->s_comm = nullptr;
+  h->s_bulk = h->s_panel = h->s_comm = h->s_aux = nullptr;
   h->own_comm_stream = false;
 }
 
@@ -367,7 +372,7 @@ void gpak_dist_destroy(gpak_dist *h) {
   if (!h) return;
   set_device(h);
   gpak_dist_engine &E = h->E;
-  if (h->s_bulk) { E.stream_sync(E.self, h->s_bulk); E.stream_sync(E.self, h->s_panel); E.stream_sync(E.self, h->s_comm); }
+  if (h->s_bulk) { E.stream_sync(E.self, h->s_bulk); E.stream_sync(E.self, h->s_panel); E.stream_sync(E.self, h->s_comm); E.stream_sync(E.self, h->s_aux); }
   release_problem(h);
   for (void *e : h->ev_sync) E.event_destroy(E.self, e);
   for (void *e : h->ev_time) E.event_destroy(E.self, e);
@@ -617,6 +622,7 @@ static int factor(gpak_dist *h, int *failed_col) {
   DCHK(E.event_record(E.self, e_fill, h->s_bulk));
   DCHK(E.stream_wait_event(E.self, h->s_panel, e_fill));
   if (h->s_comm != h->s_panel) DCHK(E.stream_wait_event(E.self, h->s_comm, e_fill));
+  DCHK(E.stream_wait_event(E.self, h->s_aux, e_fill));
   void *done = nullptr, *done_next = nullptr, *e_bulk_prev = nullptr;
   int rc = produce(h, 0, &done);
   if (rc) return rc;
@@ -652,10 +658,11 @@ static int factor(gpak_dist *h, int *failed_col) {
       e_bulk_prev = h->sync_event();
       DCHK(E.event_record(E.self, e_bulk_prev, h->s_bulk));
     }
-    // forward substitution L^-1 (y/sn2) rides along in the bulk stream's slack, and the explicit inverse of the
-    // diagonal block for the back substitution
-    DCHK(E.trsv_fwd_block(h->s_bulk, panel - J, rows, Np, J, W, h->invs[b], h->fwd_x, h->fwd_z));
-    DCHK(E.diag_inverse(h->s_bulk, panel, rows, J, J, W, h->invs[b], h->rinv[b]));
+    // forward substitution L^-1 (y/sn2) rides along on the aux stream, and the explicit inverse of the diagonal
+    // block for the back substitution
+    DCHK(E.stream_wait_event(E.self, h->s_aux, done));
+    DCHK(E.trsv_fwd_block(h->s_aux, panel - J, rows, Np, J, W, h->invs[b], h->fwd_x, h->fwd_z));
+    DCHK(E.diag_inverse(h->s_aux, panel, rows, J, J, W, h->invs[b], h->rinv[b]));
     h->rinv_ok[b] = 1;
     if (nxt >= nJ) break;
     done = done_next;
@@ -665,6 +672,9 @@ static int factor(gpak_dist *h, int *failed_col) {
   void *e_end = h->sync_event();
   DCHK(E.event_record(E.self, e_end, h->s_panel));
   DCHK(E.stream_wait_event(E.self, h->s_bulk, e_end));
+  void *e_aux = h->sync_event();
+  DCHK(E.event_record(E.self, e_aux, h->s_aux));
+  DCHK(E.stream_wait_event(E.self, h->s_bulk, e_aux));
   DCHK(T.allreduce_min_int(T.self, h->s_bulk, h->info, 1));
   int info = init;
   DCHK(E.download(E.self, h->s_bulk, &info, h->info, sizeof(int)));

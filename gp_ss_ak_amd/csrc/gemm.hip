@@ -526,10 +526,12 @@ int gpak_calibrate_impl(gpak_ctx *ctx, double *scratch, size_t scratch_bytes, do
   double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * (2.0 * 16 * 16 * 4);
   *tflops = flops / (ms * 1e-3) / 1e12;
   size_t n2 = scratch_bytes / 16;
-  hipLaunchKernelGGL(gpak_calib_store, dim3(2048), dim3(256), 0, ctx->stream, (double2 *)scratch, n2);
+  // 16384 workgroups over a buffer far larger than the 256 MiB Infinity Cache: 5.5-5.7 TB/s on MI355X (2048 workgroups
+  // over 1 GiB, the round-1 yardstick, gave 4.4-5.2; tools/store_bw.hip has the sweep)
+  hipLaunchKernelGGL(gpak_calib_store, dim3(16384), dim3(256), 0, ctx->stream, (double2 *)scratch, n2);
   GPAK_HIP(hipEventRecord(e0, ctx->stream));
   for (int r = 0; r < 4; r++)
-    hipLaunchKernelGGL(gpak_calib_store, dim3(2048), dim3(256), 0, ctx->stream, (double2 *)scratch, n2);
+    hipLaunchKernelGGL(gpak_calib_store, dim3(16384), dim3(256), 0, ctx->stream, (double2 *)scratch, n2);
   GPAK_HIP(hipEventRecord(e1, ctx->stream));
   GPAK_HIP(hipEventSynchronize(e1));
   GPAK_HIP(hipEventElapsedTime(&ms, e0, e1));

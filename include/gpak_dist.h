@@ -45,7 +45,8 @@ typedef struct gpak_dist_engine {
   int (*download)(void *self, void *stream, void *host_dst, const void *src, size_t bytes); /* complete on return  */
   int (*zero)(void *self, void *stream, void *dst, size_t bytes);
   int (*copy)(void *self, void *stream, void *dst, const void *src, size_t bytes);          /* device to device     */
-  /* kind 0: bulk stream (may leave a few compute units idle), 1: panel chain (high priority), 2: communication */
+  /* kind 0: bulk stream (may leave a few compute units idle), 1: panel chain (high priority), 2: communication,
+   * 3: auxiliary (forward substitution and diagonal-block inverses riding along) */
   void *(*stream_create)(void *self, int kind);
   void (*stream_destroy)(void *self, void *stream);
   void *(*event_create)(void *self, int timing);

@@ -175,26 +175,36 @@ def test_cli_train_then_test_config1(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("start", ["defaults", "prompted"])
-def test_cli_lbfgs_trajectory_matches_oracle_driven_restatement(orc, tmp_path, start):
+def test_cli_lbfgs_trajectory_matches_oracle_driven_restatement(orc, gp, tmp_path, start):
     """f-2 on the real objective: `gp_ss_ak train` on configs[0]'s data (N=512) runs Opt_Algs::LBFGSOptimise over
-    the HIP path; tests/lbfgs_ref.py (the independent NumPy restatement of Opt_pars.cpp:179-332, 543-974) runs
-    over the ORACLE's reference sequence -- orc_nlz_refseq (IRLS/Brent, alpha warm-started from the previous
-    evaluation like the member `Alpha`, GP_Utils.cpp:191-228) + orc_grad_ref (GradLL + getGradients as written).
-    stdout carries six digits, as the reference's `cout << fx` does; GPAK_OPT_TRACE is the 17-digit side channel.
+    the HIP path.  stdout carries six digits, as the reference's `cout << fx` does; GPAK_OPT_TRACE is the 17-digit
+    side channel (kept objective, evaluation count, kept point per iteration).  Two comparisons:
 
-    What can be asserted: the as-written algorithm STALLS (kept objective unchanged for an iteration or more: the
-    line search rejects every trial point), and the step that leaves a stall is decided at rounding level --
-    perturbing f and g by 1e-13 relative moves the next kept objective by 1e-6..1e-3 relative, and the oracle's own
-    variants (IRLS warm-started / cold / closed form) part ways there too (measured).  So the
-    reference's trajectory is only defined up to its first stall: through it, the kept objective must agree to 1e-8
-    relative, the evaluation counts exactly and the kept point to 1e-7; afterwards both must keep descending."""
+    (1) OPTIMISER: tests/lbfgs_ref.py (the independent NumPy restatement of Opt_pars.cpp:179-332, 543-974) driven
+        by the SAME objective -- the HIP path through the Python binding, on bit-identical inputs -- must reproduce
+        the CLI's trajectory BIT FOR BIT over all iterations: objective, evaluation counts, kept point.
+    (2) NUMERICS: lbfgs_ref.py driven by the ORACLE's reference sequence -- orc_nlz_refseq (IRLS/Brent, alpha
+        warm-started from the previous evaluation like the member `Alpha`, GP_Utils.cpp:191-228) + orc_grad_ref
+        (GradLL + getGradients as written).  The as-written algorithm STALLS (kept objective unchanged: the line
+        search rejects every trial point), and the step that leaves a stall is decided at rounding level:
+        perturbing f and g by 1e-13 relative moves the next kept objective by 1e-6..1e-3 relative, and the
+        oracle's own variants (IRLS warm-started / cold / closed form) part ways there too (measured; DESIGN.md
+        section 8).  So the reference's trajectory is only defined up to its first stall: through it the kept
+        objective must agree to 1e-8 relative, the evaluation counts exactly and the kept point to 1e-7."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import lbfgs_ref
+    from gp_ss_ak_amd import gpak
     build()
     N, maxit = 512, 8
-    Xr, yr = synth.drillholes_raw(N)
-    write_csv(tmp_path / "train.txt", Xr, yr, sep="\t")
+    # pre-standardised data whose extremes are EXACTLY -1 and +1: Control::prep_symmetric then finds offset 0 and
+    # scale 1 and leaves every value bit-identical, and the 17-digit text round trip is exact
+    Xs, ys = synth.drillholes(N)
+    Xs = np.asfortranarray(Xs)
+    Xs[np.unravel_index(Xs.argmax(), Xs.shape)] = 1.0
+    Xs[np.unravel_index(Xs.argmin(), Xs.shape)] = -1.0
+    ys[ys.argmax()], ys[ys.argmin()] = 1.0, -1.0
+    write_csv(tmp_path / "train.txt", Xs, ys, sep="\t")
     tr = tmp_path / "trace.txt"
     env = dict(os.environ, GPAK_MAX_ITERS=str(maxit), GPAK_OPT_TRACE=str(tr))
     cmd = [os.path.join(HOST, "gp_ss_ak"), "-v", "1"]
@@ -209,10 +219,27 @@ def test_cli_lbfgs_trajectory_matches_oracle_driven_restatement(orc, tmp_path, s
         stdin = ("y\n" + "".join(f"{v!r}\n" for i, v in enumerate(x0[:9]) if i != 7) + "y\n" + f"{x0[9]!r}\n").encode()
     cmd += ["train", "-k", "ExpAns", "-kn", "1", "-o", "LBFGS", str(tmp_path / "train.txt"), str(tmp_path / "model")]
     out = subprocess.run(cmd, env=env, cwd=tmp_path, input=stdin, stdout=subprocess.PIPE, check=True).stdout.decode()
+    stats = np.loadtxt(str(tmp_path / "model") + "_Statistics.txt", delimiter=",")
+    assert np.all(stats[:, 0] == 0.0) and np.all(stats[:, 1] == 1.0)     # the standardisation was the identity
     rows = [[float(v) for v in line.split()] for line in open(tr)]
     printed = [float(line.split("-logL:")[1]) for line in out.splitlines() if line.startswith("Iteration:")]
-    # what the CLI sees: the text round trip at 17 digits is exact, then Control::prep_symmetric
-    Xs, ys, _ = synth.symmetric_standardise(Xr, yr)
+    assert len(rows) == maxit and all(int(r[0]) == k + 1 for k, r in enumerate(rows))
+    cli = [r[1] for r in rows]
+
+    # (1) the same objective under the independent restatement of the optimiser
+    gp.set_train(Xs, ys)
+
+    def fg_hip(x):
+        gp.set_params(np.array(x[:8], dtype=float), float(x[8]), float(x[9]), gpak.DIST_DIRECT)
+        return gp.logLikelihood(), gp.GradLL()
+
+    same = []
+    lbfgs_ref.lbfgs_optimise(fg_hip, x0, maxit, trace=same)
+    assert [h for h, _, _ in same] == cli                                  # bit for bit, stalls included
+    assert [n for _, n, _ in same] == [int(r[2]) for r in rows]
+    assert all(np.array_equal(xk, np.array(r[3:])) for (_, _, xk), r in zip(same, rows))
+
+    # (2) the oracle's reference sequence under the same restatement
     state = {"alpha": None}
 
     def fg(x):
@@ -225,7 +252,6 @@ def test_cli_lbfgs_trajectory_matches_oracle_driven_restatement(orc, tmp_path, s
 
     ref = []
     lbfgs_ref.lbfgs_optimise(fg, x0, maxit, trace=ref)
-    assert len(rows) == len(ref) == maxit
     hist = [r[0] for r in ref]
     first_stall = next(k for k in range(1, maxit) if hist[k] == hist[k - 1])
     agree = 0
@@ -234,13 +260,13 @@ def test_cli_lbfgs_trajectory_matches_oracle_driven_restatement(orc, tmp_path, s
             break
         agree += 1
     print(f"\n{start}: first stall at iteration {first_stall + 1}; CLI and oracle-driven trajectories agree (1e-8, same "
-          f"evaluation counts) through iteration {agree} of {maxit}\n  CLI    {[r[1] for r in rows]}\n  oracle {hist}")
+          f"evaluation counts) through iteration {agree} of {maxit}\n  CLI    {cli}\n  evals  {[int(r[2]) for r in rows]}"
+          f"\n  oracle {hist}\n  evals  {[n for _, n, _ in ref]}")
     assert agree >= first_stall + 1
-    assert int(rows[0][0]) == 1 and all(int(r[0]) == k + 1 for k, r in enumerate(rows))
-    cli = [r[1] for r in rows]
     assert all(b <= a for a, b in zip(cli, cli[1:])) and cli[-1] < cli[0] - 1.0      # kept objective never increases
     for p, row in zip(printed, rows):                             # the stdout lines are the same numbers at 6 digits
         assert abs(p - row[1]) <= 1e-5 * abs(row[1])
+    gp.set_params(E, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
 
 
 @pytest.mark.gpu
