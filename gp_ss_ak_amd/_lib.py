@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgpak_hip.so")
 
 # every symbol include/gpak.h declares (tests check the header and this list agree)
 SYMBOLS = [
-    "gpak_create", "gpak_destroy", "gpak_last_error", "gpak_global_error", "gpak_set_train",
+    "gpak_create", "gpak_create_multi", "gpak_n_gpus", "gpak_destroy", "gpak_last_error", "gpak_global_error", "gpak_set_train",
     "gpak_set_params", "gpak_set_kernel", "gpak_set_option", "gpak_gram", "gpak_compute_k", "gpak_factor",
     "gpak_get_chol_upper", "gpak_failed_column", "gpak_solve_alpha", "gpak_solve_chol", "gpak_nlz",
     "gpak_nlz_terms", "gpak_predict", "gpak_grad", "gpak_grad_hyb", "gpak_timing", "gpak_calibrate",
@@ -23,7 +23,8 @@ class PhaseTimes(C.Structure):
                 ("nlz_ms", C.c_double), ("predict_ms", C.c_double), ("grad_ms", C.c_double),
                 ("trailing_ms", C.c_double), ("trailing_flops", C.c_double),
                 ("trailing_launches", C.c_int), ("gram_bytes", C.c_double), ("n", C.c_int),
-                ("n_padded", C.c_int)]
+                ("n_padded", C.c_int), ("trailing_bytes", C.c_double), ("kmatvec_ms", C.c_double),
+                ("accumulated_ms", C.c_double * 4), ("evaluations", C.c_int)]
 
 
 _lib = None
@@ -45,6 +46,8 @@ def load():
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p
     lib.gpak_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    lib.gpak_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_int]
+    lib.gpak_n_gpus.argtypes = [vp]
     lib.gpak_destroy.argtypes = [vp]
     lib.gpak_destroy.restype = None
     lib.gpak_last_error.argtypes = [vp]

@@ -9,7 +9,22 @@
 #include "gpak_internal.h"
 
 int gpak_calibrate_impl(gpak_ctx *ctx, double *scratch, size_t scratch_bytes, double *tflops, double *gbs);
-int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var);
+int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var, const double *pool_sum,
+                      long pool_M);
+// multi.hip
+#include <functional>
+int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision, std::string &err);
+void gpak_multi_destroy(gpak_multi *g);
+const char *gpak_multi_error(gpak_multi *g);
+int gpak_multi_set_train(gpak_multi *g, const double *X, const double *y, int N, int d);
+int gpak_multi_set_params(gpak_multi *g, const double *expans, double bias, double sn2, int dist_mode);
+int gpak_multi_nlz(gpak_multi *g, double *nlz, double *quad, double *sumlp, double *logdet);
+int gpak_multi_alpha(gpak_multi *g, double *alpha_host);
+int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f);
+int gpak_multi_predict(gpak_multi *g, const double *Xte, long M, int d, double *mean, double *var);
+int gpak_multi_timing(gpak_multi *g, gpak_phase_times *out);
+int gpak_multi_n(gpak_multi *g);
+#define GPAK_MULTI_ERR(rc_) do { int v_ = (rc_); if (v_) ctx->err = gpak_multi_error(ctx->multi); return v_; } while (0)
 int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k);
 int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng);
 
@@ -136,7 +151,7 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
       }
     }
   }
-  for (int i = 0; i < 8; i++) hipEventCreate(&ctx->ev[i]);
+  for (int i = 0; i < 10; i++) hipEventCreate(&ctx->ev[i]);
   hipMalloc(&ctx->dRed, sizeof(double) * 64);
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
   if (const char *pe = getenv("GPAK_FWD_IN_FACTOR")) ctx->fwd_in_factor = atoi(pe) != 0;
@@ -146,15 +161,31 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   return GPAK_OK;
 }
 
+int gpak_create_multi(gpak_ctx **out, int n_gpus, const int *devices, int precision) {
+  if (!out || n_gpus < 1) return GPAK_EINVAL;
+  *out = nullptr;
+  if (precision != GPAK_F64 && precision != GPAK_F32) { g_global_err = "precision must be GPAK_F64 or GPAK_F32"; return GPAK_EINVAL; }
+  gpak_multi *g = nullptr;
+  int rc = gpak_multi_create(&g, n_gpus, devices, precision, g_global_err);
+  if (rc) return rc;
+  gpak_ctx *ctx = new gpak_ctx();
+  ctx->multi = g;
+  ctx->precision = precision;
+  memset(&ctx->times, 0, sizeof(ctx->times));
+  *out = ctx;
+  return GPAK_OK;
+}
+
 void gpak_destroy(gpak_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->multi) { gpak_multi_destroy(ctx->multi); delete ctx; return; }
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   release_train(ctx);
   gpak_predict_release(ctx);
   if (ctx->dRed) hipFree(ctx->dRed);
   if (ctx->dInfo) hipFree(ctx->dInfo);
-  for (int i = 0; i < 8; i++) hipEventDestroy(ctx->ev[i]);
+  for (int i = 0; i < 10; i++) hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   for (auto e : ctx->ev_sync) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream_hi);
@@ -168,6 +199,7 @@ const char *gpak_last_error(const gpak_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 int gpak_set_option(gpak_ctx *ctx, int option, long value) {
   if (!ctx) return GPAK_EINVAL;
+  if (ctx->multi) return GPAK_OK;   // schedule options of the single-GPU factorisation: nothing to set on a group
   switch (option) {
     case GPAK_OPT_MEMOISE: ctx->memoise = value != 0; return GPAK_OK;
     case GPAK_OPT_NB_OUTER:
@@ -183,6 +215,7 @@ int gpak_set_option(gpak_ctx *ctx, int option, long value) {
 
 int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d) {
   if (!ctx || !X || !y || N <= 0) return GPAK_EINVAL;
+  if (ctx->multi) { ctx->N = N; ctx->d = d; GPAK_MULTI_ERR(gpak_multi_set_train(ctx->multi, X, y, N, d)); }
   // d = 3: x, y, z; d = 4: + rock-type column with its own inverse width (Kernel.cpp:1411-1424)
   if (d != 3 && d != 4) { ctx->err = "inputs must have 3 or 4 columns"; return GPAK_ENOTIMPL; }
   GPAK_HIP(hipSetDevice(ctx->device));
@@ -224,6 +257,7 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
                             hipMemcpyHostToDevice, ctx->stream));
   GPAK_HIP(hipMemcpyAsync(ctx->dy, y, sizeof(double) * N, hipMemcpyHostToDevice, ctx->stream));
   GPAK_HIP(hipStreamSynchronize(ctx->stream));
+  memset(&ctx->times, 0, sizeof(ctx->times));
   ctx->times.n = N; ctx->times.n_padded = Np;
   ctx->U.n = 0;  // transformed points are rebuilt on the next use
   return GPAK_OK;
@@ -232,6 +266,7 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
 int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2, int dist_mode) {
   if (!ctx || !expans) return GPAK_EINVAL;
   if (dist_mode != GPAK_DIST_EXPANSION && dist_mode != GPAK_DIST_DIRECT) { ctx->err = "bad dist_mode"; return GPAK_EINVAL; }
+  if (ctx->multi) { ctx->sn2 = sn2; GPAK_MULTI_ERR(gpak_multi_set_params(ctx->multi, expans, bias, sn2, dist_mode)); }
   bool same = ctx->have_params && memcmp(expans, ctx->expans, sizeof(double) * 8) == 0 && bias == ctx->bias &&
               sn2 == ctx->sn2 && dist_mode == ctx->dist_mode;
   memcpy(ctx->expans, expans, sizeof(double) * 8);
@@ -263,6 +298,7 @@ int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2
 int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *pars, double bias, double white,
                     double sn2, int dist_mode) {
   if (!ctx || !kinds || !pars || nterms < 1 || nterms > GPAK_MAX_TERMS) return GPAK_EINVAL;
+  if (ctx->multi) { ctx->err = "a multi-GPU context handles the ExpAns(+Bias) composition (gpak_set_params)"; return GPAK_ENOTIMPL; }
   if (dist_mode != GPAK_DIST_EXPANSION && dist_mode != GPAK_DIST_DIRECT) { ctx->err = "bad dist_mode"; return GPAK_EINVAL; }
   KernParams kp;
   memset(&kp, 0, sizeof(kp));
@@ -340,6 +376,9 @@ static int ensure_factor(gpak_ctx *ctx) {
   ctx->times.gram_ms = ms;
   GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
   ctx->times.factor_ms = ms;
+  ctx->times.accumulated_ms[0] += ctx->times.gram_ms;
+  ctx->times.accumulated_ms[1] += ctx->times.factor_ms;
+  ctx->times.evaluations++;
   ctx->times.gram_bytes = 8.0 * ((double)ctx->Np * (ctx->Np + GPAK_TILE) / 2.0);
   if (rc == GPAK_ENOTPD) {
     ctx->mstate = gpak_ctx::M_NONE;
@@ -373,6 +412,7 @@ static int ensure_alpha(gpak_ctx *ctx) {
   float ms = 0;
   GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
   ctx->times.solve_ms = ms;
+  ctx->times.accumulated_ms[2] += ms;
   ctx->alpha_ok = true;
   return GPAK_OK;
 }
@@ -387,6 +427,7 @@ static int ensure_nlz(gpak_ctx *ctx) {
   GPAK_HIP(hipEventRecord(ctx->ev[5], st));
   int splits = gpak_kmatvec_splits(ctx->N, ctx->N);
   gpak_launch_kmatvec(st, ctx->U, 0, ctx->N, ctx->dAlpha, ctx->U, ctx->kp, scratch, splits, f);  // f = K*Alpha
+  GPAK_HIP(hipEventRecord(ctx->ev[8], st));
   if (ctx->kp.white != 0.0) gpak_launch_axpy(st, ctx->N, ctx->kp.white, ctx->dAlpha, f);  // Kern_White diagonal
   gpak_launch_logdet(st, ctx->N, ctx->dM, ctx->ld, ctx->dRed);
   gpak_launch_nlz_terms(st, ctx->N, ctx->dy, f, ctx->dAlpha, ctx->sn2, ctx->dRed);
@@ -397,6 +438,9 @@ static int ensure_nlz(gpak_ctx *ctx) {
   float ms = 0;
   GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]));
   ctx->times.nlz_ms = ms;
+  ctx->times.accumulated_ms[3] += ms;
+  GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[8]));
+  ctx->times.kmatvec_ms = ms;
   ctx->logdet = red[0]; ctx->quad = red[1]; ctx->sumlp = red[2];
   ctx->nlz = ctx->quad - ctx->sumlp + ctx->logdet;  // GP_Utils.cpp:1159
   ctx->nlz_ok = true;
@@ -415,6 +459,7 @@ extern "C" {
 
 int gpak_gram(gpak_ctx *ctx, double *K_host, double *D2_host) {
   if (!ctx) return GPAK_EINVAL;
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_gram(c, K_host, D2_host); }));
   GPAK_HIP(hipSetDevice(ctx->device));
   int rc = gpak_ensure_U(ctx);
   if (rc) return rc;
@@ -439,6 +484,8 @@ int gpak_gram(gpak_ctx *ctx, double *K_host, double *D2_host) {
 int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int m, int d, double *K_host,
                    double *D2_host) {
   if (!ctx || !X1 || !X2 || n <= 0 || m <= 0) return GPAK_EINVAL;
+  if (ctx->multi)
+    GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_compute_k(c, X1, n, X2, m, d, K_host, D2_host); }));
   if (d != 3 && d != 4) { ctx->err = "inputs must have 3 or 4 columns"; return GPAK_ENOTIMPL; }
   if (!ctx->have_params) { ctx->err = "no parameters (gpak_set_params)"; return GPAK_ESTATE; }
   GPAK_HIP(hipSetDevice(ctx->device));
@@ -486,13 +533,16 @@ int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int
 
 int gpak_factor(gpak_ctx *ctx) {
   if (!ctx) return GPAK_EINVAL;
+  if (ctx->multi) { double v; GPAK_MULTI_ERR(gpak_multi_nlz(ctx->multi, &v, nullptr, nullptr, nullptr)); }
   return ensure_factor(ctx);
 }
 
 int gpak_failed_column(const gpak_ctx *ctx) { return ctx ? ctx->failed_col : 0; }
+int gpak_n_gpus(const gpak_ctx *ctx) { return !ctx ? 0 : (ctx->multi ? gpak_multi_n(ctx->multi) : 1); }
 
 int gpak_get_chol_upper(gpak_ctx *ctx, double *R_host) {
   if (!ctx || !R_host) return GPAK_EINVAL;
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_get_chol_upper(c, R_host); }));
   int rc = ensure_factor(ctx);
   if (rc) return rc;
   const int N = ctx->N;
@@ -506,6 +556,7 @@ int gpak_get_chol_upper(gpak_ctx *ctx, double *R_host) {
 
 int gpak_solve_alpha(gpak_ctx *ctx, double *alpha_host) {
   if (!ctx) return GPAK_EINVAL;
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_alpha(ctx->multi, alpha_host));
   int rc = ensure_alpha(ctx);
   if (rc) return rc;
   if (alpha_host) {
@@ -517,6 +568,7 @@ int gpak_solve_alpha(gpak_ctx *ctx, double *alpha_host) {
 
 int gpak_solve_chol(gpak_ctx *ctx, double *X_host, int k) {
   if (!ctx || !X_host || k <= 0) return GPAK_EINVAL;
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_solve_chol(c, X_host, k); }));
   int rc = ensure_factor(ctx);
   if (rc) return rc;
   return gpak_solve_chol_impl(ctx, X_host, k);
@@ -524,6 +576,7 @@ int gpak_solve_chol(gpak_ctx *ctx, double *X_host, int k) {
 
 int gpak_nlz(gpak_ctx *ctx, double *nlz) {
   if (!ctx || !nlz) return GPAK_EINVAL;
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_nlz(ctx->multi, nlz, nullptr, nullptr, nullptr));
   int rc = ensure_nlz(ctx);
   if (rc) {
     *nlz = std::numeric_limits<double>::quiet_NaN();  // GP_Utils.cpp:1146, 1157
@@ -535,6 +588,7 @@ int gpak_nlz(gpak_ctx *ctx, double *nlz) {
 
 int gpak_nlz_terms(gpak_ctx *ctx, double *quad, double *sumlp, double *logdet) {
   if (!ctx) return GPAK_EINVAL;
+  if (ctx->multi) { double v; GPAK_MULTI_ERR(gpak_multi_nlz(ctx->multi, &v, quad, sumlp, logdet)); }
   int rc = ensure_nlz(ctx);
   if (rc) return rc;
   if (quad) *quad = ctx->quad;
@@ -545,12 +599,18 @@ int gpak_nlz_terms(gpak_ctx *ctx, double *quad, double *sumlp, double *logdet) {
 
 int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, double *var, int compat_flags) {
   if (!ctx || !Xte || !mean || M <= 0) return GPAK_EINVAL;
-  if (d != ctx->d) { ctx->err = "test points must have as many columns as the training set"; return GPAK_EINVAL; }
-  // _postVar calls logLikelihood() (GP_Utils.cpp:980); _postMean calls updateAlpha() (:961)
-  int rc = ensure_nlz(ctx);
-  if (rc) return rc;
-  rc = gpak_predict_impl(ctx, Xte, M, mean, var);
-  if (rc) return rc;
+  int rc;
+  if (ctx->multi) {
+    rc = gpak_multi_predict(ctx->multi, Xte, M, d, mean, var);
+    if (rc) { ctx->err = gpak_multi_error(ctx->multi); return rc; }
+  } else {
+    if (d != ctx->d) { ctx->err = "test points must have as many columns as the training set"; return GPAK_EINVAL; }
+    // _postVar calls logLikelihood() (GP_Utils.cpp:980); _postMean calls updateAlpha() (:961)
+    rc = ensure_nlz(ctx);
+    if (rc) return rc;
+    rc = gpak_predict_impl(ctx, Xte, M, mean, var, nullptr, 0);
+    if (rc) return rc;
+  }
   if (var) {
     if (compat_flags & GPAK_COMPAT_VARCLAMP) {
       // GP_Utils.cpp:1002-1003: `uvec ind = varSigma < 0; varSigma.elem(ind) = 0` -- the 0/1
@@ -571,6 +631,7 @@ int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, 
 
 int gpak_grad(gpak_ctx *ctx, double *g) {
   if (!ctx || !g) return GPAK_EINVAL;
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_grad(c, g); }));
   if (!ctx->expans_only) { ctx->err = "gpak_grad handles the ExpAns(+Bias) composition only"; return GPAK_ENOTIMPL; }
   int rc = ensure_nlz(ctx);  // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
   if (rc) return rc;
@@ -579,6 +640,7 @@ int gpak_grad(gpak_ctx *ctx, double *g) {
 
 int gpak_grad_hyb(gpak_ctx *ctx, double *g, int ng) {
   if (!ctx || !g) return GPAK_EINVAL;
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_grad_hyb(c, g, ng); }));
   int rc = ensure_nlz(ctx);
   if (rc) return rc;
   return gpak_grad_impl(ctx, g, ng);
@@ -586,12 +648,15 @@ int gpak_grad_hyb(gpak_ctx *ctx, double *g, int ng) {
 
 int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out) {
   if (!ctx || !out) return GPAK_EINVAL;
+  if (ctx->multi) return gpak_multi_timing(ctx->multi, out);
   *out = ctx->times;
   return GPAK_OK;
 }
 
 int gpak_calibrate(gpak_ctx *ctx, double *mfma_f64_tflops, double *hbm_write_gbs) {
   if (!ctx || !mfma_f64_tflops || !hbm_write_gbs) return GPAK_EINVAL;
+  if (ctx->multi)
+    GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_calibrate(c, mfma_f64_tflops, hbm_write_gbs); }));
   GPAK_HIP(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)4 << 30;
   double *scratch = nullptr;

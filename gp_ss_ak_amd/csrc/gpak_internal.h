@@ -47,7 +47,10 @@ struct DevPoints {
   int cap = 0;  // allocated points (multiple of GPAK_TILE)
 };
 
+struct gpak_multi;   // multi.hip: one process driving several GPUs (gpak_create_multi)
+
 struct gpak_ctx {
+  gpak_multi *multi = nullptr;   // set: every call is forwarded to the group, the fields below are unused
   int device = 0;
   int precision = GPAK_F64;
   hipStream_t stream = nullptr;     // main stream: fill, bulk trailing updates, solves
@@ -117,7 +120,7 @@ struct gpak_ctx {
 
   // timing
   gpak_phase_times times;
-  hipEvent_t ev[8];
+  hipEvent_t ev[10];
   std::vector<hipEvent_t> ev_pool;   // timing events around the trailing updates
   std::vector<hipEvent_t> ev_sync;   // cross-stream dependencies of the look-ahead pipeline
 };

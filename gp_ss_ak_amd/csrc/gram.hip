@@ -322,13 +322,71 @@ int gpak_kmatvec_splits(int nP, int nQ) {
   return s < 1 ? 1 : s;
 }
 
+// The default composition (one exp(-sqrt(D2)) term + bias) with the table exp of the fill: 32 instead of 47 fp64
+// instruction slots per kernel evaluation; fp64-VALU bound (N^2 evaluations, nothing stored).
+template <int MODE, bool D4>
+__global__ __launch_bounds__(256) void gpak_kmatvec1_part_f64(const double *__restrict__ P, int capP, int nP, int p_off,
+                                                               const double *__restrict__ w, int per_split,
+                                                               const double *__restrict__ Q, int capQ, int nQ,
+                                                               double var2, double bias, double *__restrict__ part,
+                                                               int part_ld) {
+  __shared__ double sp[GPAK_PT + 1][KMV_CHUNK];
+  __shared__ double tab[GPAK_EXPTAB_N];
+  if (threadIdx.x < GPAK_EXPTAB_N) tab[threadIdx.x] = gpak_exp2_tab[threadIdx.x];
+  int j[KMV_COLS];
+  bool ok[KMV_COLS];
+  double b[KMV_COLS][GPAK_PT];
+#pragma unroll
+  for (int q = 0; q < KMV_COLS; q++) {
+    j[q] = (blockIdx.x * KMV_COLS + q) * 256 + threadIdx.x;
+    ok[q] = j[q] < nQ;
+#pragma unroll
+    for (int c = 0; c < GPAK_PT; c++) b[q][c] = ok[q] ? PARR(Q, capQ, 0, c)[j[q]] : 0.0;
+  }
+  const int i_begin = blockIdx.y * per_split;
+  const int i_end = min(nP, i_begin + per_split);
+  double acc[KMV_COLS], wsum = 0.0;
+#pragma unroll
+  for (int q = 0; q < KMV_COLS; q++) acc[q] = 0.0;
+  for (int i0 = i_begin; i0 < i_end; i0 += KMV_CHUNK) {
+    const int i = i0 + threadIdx.x;
+    const bool v = i < i_end;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < GPAK_PT; c++) sp[c][threadIdx.x] = v ? PARR(P, capP, 0, c)[p_off + i] : 0.0;
+    sp[GPAK_PT][threadIdx.x] = v ? w[i] : 0.0;  // zero weight masks the tail
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < KMV_CHUNK; k++) {
+      const double p0 = sp[0][k], p1 = sp[1][k], p2 = sp[2][k], p3 = sp[3][k], p4 = sp[4][k], wk = sp[GPAK_PT][k];
+      wsum += wk;
+#pragma unroll
+      for (int q = 0; q < KMV_COLS; q++)   // the bias term is added once at the end: sum_k w_k (bias + var2 e_k)
+        acc[q] = fma(wk, gpak_k1<MODE, D4>(p0, p1, p2, p3, p4, b[q][0], b[q][1], b[q][2], b[q][3], b[q][4], var2, 0.0, tab),
+                     acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KMV_COLS; q++)
+    if (ok[q]) part[(size_t)blockIdx.y * part_ld + j[q]] = fma(bias, wsum, acc[q]);
+}
+
 // source points [p_off, p_off + np) of P with weights w[0..np)
 void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, int p_off, int np, const double *w, const DevPoints &Q,
                          const KernParams &kp, double *scratch, int splits, double *out) {
   int per = (np + splits - 1) / splits;
   per = (per + KMV_CHUNK - 1) / KMV_CHUNK * KMV_CHUNK;
   dim3 grid((Q.n + 256 * KMV_COLS - 1) / (256 * KMV_COLS), splits);
-  if (kp.nterms == 1)
+  static const bool fast_off = getenv("GPAK_FILL_FAST") && atoi(getenv("GPAK_FILL_FAST")) == 0;
+  if (kp.nterms == 1 && kp.term[0].profile == GPAK_PROFILE_EXPSQRT && !fast_off) {
+#define GPAK_KMV1(MODE_, D4_)                                                                                          \
+  hipLaunchKernelGGL((gpak_kmatvec1_part_f64<MODE_, D4_>), grid, dim3(256), 0, st, P.base, P.cap, np, p_off, w, per, Q.base, \
+                     Q.cap, Q.n, kp.term[0].var2, kp.bias, scratch, Q.cap)
+    const bool d4 = kp.d == 4;
+    if (kp.mode == GPAK_DIST_DIRECT) { if (d4) GPAK_KMV1(GPAK_DIST_DIRECT, true); else GPAK_KMV1(GPAK_DIST_DIRECT, false); }
+    else { if (d4) GPAK_KMV1(GPAK_DIST_EXPANSION, true); else GPAK_KMV1(GPAK_DIST_EXPANSION, false); }
+#undef GPAK_KMV1
+  } else if (kp.nterms == 1)
     hipLaunchKernelGGL(gpak_kmatvec_part_f64<1>, grid, dim3(256), 0, st, P.base, P.cap, np, p_off, w, per, Q.base,
                        Q.cap, Q.n, kp, scratch, Q.cap);
   else

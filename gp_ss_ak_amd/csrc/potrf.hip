@@ -371,7 +371,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
 
   size_t ev_used = 0;
   int done512 = 0;
-  double tflops = 0.0;
+  double tflops = 0.0, tbytes = 0.0;
   int tl = 0;
   for (int b = 0; b < nJ; b++) {
     const int J = Js[b], W = Js[b + 1] - J;
@@ -425,6 +425,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
       }
       const double mt = (Np - J2) / PB;
       tflops += mt * (mt + 1) / 2.0 * 2.0 * PB * PB * W;  // lower tiles only
+      tbytes += mt * (mt + 1) / 2.0 * 2.0 * PB * PB * 8.0; // each C tile read once and written once
       tl++;
     }
     GPAK_HIP(hipEventRecord(EU[b], su));
@@ -439,6 +440,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   GPAK_HIP(hipMemcpyAsync(&info, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, su));
   GPAK_HIP(hipStreamSynchronize(su));
   ctx->times.trailing_flops = tflops;
+  ctx->times.trailing_bytes = tbytes;
   ctx->times.trailing_launches = tl;
   ctx->times.trailing_ms = 0.0;
   if (ctx->profile) {

@@ -149,7 +149,10 @@ static void forward_subst_batch_f32(gpak_ctx *ctx, float *Wt, long ldw, int mbp)
   }
 }
 
-int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var) {
+// pool_sum / pool_M: column sums and count of the WHOLE test set when Xte is a slice of it (multi-GPU prediction
+// shards the test points; the pooled mean of Kernel.cpp:1391-1392 is over all of them), or nullptr
+int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var, const double *pool_sum,
+                      long pool_M) {
   GPAK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int N = ctx->N, Np = ctx->Np;
@@ -173,7 +176,8 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
     for (long i = 0; i < M; i++) s2[k] += Xte[i + (size_t)k * M];
   KernParams kp = ctx->kp;
   kp.d = ctx->d;
-  gpak_pooled_mean(ctx->xsum, N, s2, M, kp.mu);
+  if (pool_sum) gpak_pooled_mean(ctx->xsum, N, pool_sum, pool_M, kp.mu);
+  else gpak_pooled_mean(ctx->xsum, N, s2, M, kp.mu);
   gpak_launch_transform(st, ctx->dX, Np, N, kp, ctx->Upred);
 
   const double kD = ctx->kdiag;  // diag_Compute of the composition, Kernel.cpp:127-136, 780-783, 328-332

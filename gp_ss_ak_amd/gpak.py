@@ -38,10 +38,16 @@ def _f(a):
 class Gpak:
     """One context = one GPU. Mirrors the slice of GP_utils that sits on the hot path."""
 
-    def __init__(self, device=0, precision=F64):
+    def __init__(self, device=0, precision=F64, devices=None):
+        """devices: a list of HIP ordinals -> gpak_create_multi (one process driving several GPUs; an ordinal may
+        repeat on a test box, the ranks then share that GPU)."""
         self._lib = _lib.load()
         h = C.c_void_p()
-        rc = self._lib.gpak_create(C.byref(h), device, precision)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(v) for v in devices])
+            rc = self._lib.gpak_create_multi(C.byref(h), len(devices), arr, precision)
+        else:
+            rc = self._lib.gpak_create(C.byref(h), device, precision)
         if rc != OK:
             raise GpakError(rc, self._lib.gpak_global_error().decode())
         self._h = h
@@ -154,7 +160,9 @@ class Gpak:
     def timing(self):
         t = _lib.PhaseTimes()
         self._check(self._lib.gpak_timing(self._h, C.byref(t)))
-        return {name: getattr(t, name) for name, _ in t._fields_}
+        out = {name: getattr(t, name) for name, _ in t._fields_}
+        out["accumulated_ms"] = list(t.accumulated_ms)
+        return out
 
     def calibrate(self):
         a, b = C.c_double(), C.c_double()

@@ -12,6 +12,15 @@ Control::Control(int arc, char **arv) : argc(arc), argv(arv) {
     if (isArg("-v", "--verboseL")) { incArg(); verbose = getIntArg(); }
     else if (isArg("-pm", "--prepMethod")) { incArg(); prepareM = getIntArg(); }
     else if (isArg("-np", "--no-prompt")) { no_prompt = true; }
+    // SURVEY.md section 5 "Config / flags": device-side options of the HIP path (not reference flags)
+    else if (isArg("-g", "--gpus")) { incArg(); gpus = getIntArg(); if (gpus < 1) ErrorTermination("--gpus needs a positive count"); }
+    else if (isArg("-p", "--precision")) {
+      incArg();
+      if (getArg() == "f64") precision = 0;
+      else if (getArg() == "f32") precision = 1;
+      else ErrorTermination("--precision takes f64 or f32");
+    }
+    else if (isArg("-t", "--timing")) { incArg(); timing_file = getArg(); }   // "-" = stdout
     else break;
     incArg();
   }

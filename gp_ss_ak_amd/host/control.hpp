@@ -45,6 +45,9 @@ class Control {
   int verbose = 0;
   int prepareM = 1;
   bool no_prompt = false;
+  int gpus = 1;                  // --gpus n: block-column-cyclic multi-GPU context (gpak_create_multi)
+  int precision = 0;             // --precision f64|f32: GPAK_F64 / GPAK_F32 (fp32 prediction work)
+  std::string timing_file;       // --timing file|-: JSON of gpak_phase_times after the verb
   std::string mode = "gp";
   mat params, MinData, MaxData, MeanData, StData;
   double MaxTotalin = 0, MinTotalin = 0, MaxTotalo = 0, MinTotalo = 0;

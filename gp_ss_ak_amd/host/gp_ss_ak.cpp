@@ -1,6 +1,8 @@
 // gp_ss_ak.cpp -- the reference's command line (gp_ss_ak.cpp:14-557) over the HIP hot path:
-//   gp_ss_ak [-v n] [-pm m] [-np] train [-k ExpAns] [-kn 1] [-o LBFGS] [-# iters] train.txt [model]
-//   gp_ss_ak [-v n] [-pm m]       test  test.txt model train.txt [out_file]
+//   gp_ss_ak [-v n] [-pm m] [-np] [device options] train [-k ExpAns] [-kn 1] [-o LBFGS] [-# iters] train.txt [model]
+//   gp_ss_ak [-v n] [-pm m]       [device options] test  test.txt model train.txt [out_file]
+// device options (not reference flags): --gpus n (multi-GPU context), --precision f64|f32
+// (fp32 prediction work), --timing file|- (JSON of the context's phase times after the verb).
 // Same verbs, flags and files (<model>, <model>_Statistics.txt, <model>_predict.txt,
 // <model>_gnu.plt); -np/--no-prompt skips the two interactive stdin questions of `train`
 // (gp_ss_ak.cpp:235-285) and the gnuplot call of `test` (:503-505).
@@ -16,7 +18,14 @@
 
 class GP_Cntrl : public Control {
  public:
-  GP_Cntrl(int argc, char **argv) : Control(argc, argv) {}
+  GP_Cntrl(int argc, char **argv) : Control(argc, argv) { GP_utils::setDeviceOptions(precision, gpus); }
+  void writeTiming(const GP_utils &m) const {
+    if (timing_file.empty()) return;
+    const std::string j = m.timingJson();
+    if (timing_file == "-") { std::cout << "TIMING " << j << std::endl; return; }
+    std::ofstream out(timing_file.c_str());
+    out << j << "\n";
+  }
   void train();
   void test();
   void Help() const;
@@ -127,6 +136,7 @@ void GP_Cntrl::train() {
   vy /= y.n_elem;
   if (getVerbose() > 0) { std::cout << "Mean Square Error of training: " << mse << "\n"; std::cout << "Var MSE Train: " << vy << "\n"; }
   else { std::cout << mse << "\n" << vy << "\n"; }
+  writeTiming(*GPModel);
   delete GPModel;
   exit(0);
 }
@@ -202,6 +212,7 @@ void GP_Cntrl::test() {
     std::string cmd = "gnuplot -persist " + modelName + "_gnu.plt";
     if (system(cmd.c_str()) != 0) std::cerr << "gnuplot failed" << std::endl;
   }
+  writeTiming(*GPModel);
   delete GPModel;
   exit(0);
 }

@@ -3,22 +3,44 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <vector>
 
 #include "../../include/gpak.h"
 
-GP_utils::GP_utils() {
-  if (gpak_create(&ctx, getenv("GPAK_DEVICE") ? atoi(getenv("GPAK_DEVICE")) : 0, GPAK_F64) != GPAK_OK)
-    gpak_host_fatal("gpak_create", nullptr);
+int GP_utils::default_precision = GPAK_F64;
+int GP_utils::default_gpus = 1;
+
+void GP_utils::create_ctx() {
+  int rc;
+  if (default_gpus > 1) rc = gpak_create_multi(&ctx, default_gpus, nullptr, default_precision);
+  else rc = gpak_create(&ctx, getenv("GPAK_DEVICE") ? atoi(getenv("GPAK_DEVICE")) : 0, default_precision);
+  if (rc != GPAK_OK) gpak_host_fatal(default_gpus > 1 ? "gpak_create_multi" : "gpak_create", nullptr);
 }
+
+std::string GP_utils::timingJson() const {
+  gpak_phase_times t;
+  if (gpak_timing(ctx, &t) != GPAK_OK) return "{}";
+  char buf[1024];
+  snprintf(buf, sizeof buf,
+           "{\"n\": %d, \"n_padded\": %d, \"evaluations\": %d, \"last\": {\"gram_ms\": %.6g, \"factor_ms\": %.6g, "
+           "\"solve_ms\": %.6g, \"nlz_ms\": %.6g, \"kmatvec_ms\": %.6g, \"predict_ms\": %.6g, \"grad_ms\": %.6g}, "
+           "\"accumulated\": {\"gram_ms\": %.6g, \"factor_ms\": %.6g, \"solve_ms\": %.6g, \"nlz_ms\": %.6g}, "
+           "\"precision\": \"%s\", \"gpus\": %d}",
+           t.n, t.n_padded, t.evaluations, t.gram_ms, t.factor_ms, t.solve_ms, t.nlz_ms, t.kmatvec_ms, t.predict_ms,
+           t.grad_ms, t.accumulated_ms[0], t.accumulated_ms[1], t.accumulated_ms[2], t.accumulated_ms[3],
+           default_precision == GPAK_F32 ? "f32" : "f64", default_gpus);
+  return buf;
+}
+
+GP_utils::GP_utils() { create_ctx(); }
 
 GP_utils::GP_utils(Kernels *kernel, mat Xin, mat Yin, int, int likeLtype, int, unsigned int numhyper,
                    unsigned int numlik_par, unsigned int numMF_par, int verbos)
     : Xinp(Xin), yTarg(Yin), KerenlW(kernel) {
-  if (gpak_create(&ctx, getenv("GPAK_DEVICE") ? atoi(getenv("GPAK_DEVICE")) : 0, GPAK_F64) != GPAK_OK)
-    gpak_host_fatal("gpak_create", nullptr);
+  create_ctx();
   setNumMFpar(numMF_par);
   setNumlikfpar(numlik_par);
   setNumCovpar(numhyper);

@@ -118,6 +118,10 @@ class GP_utils : public Modeling, public Opt_Algs, public StreamIntfce {
   void setLikelihoodType(int v) { likelihoodType = v; }
   int getLikelihoodType() const { return likelihoodType; }
   void setCompatFlags(int f) { compat = f; }
+  // device-side options of every GP_utils constructed afterwards (the CLI's --precision / --gpus)
+  static void setDeviceOptions(int precision, int gpus) { default_precision = precision; default_gpus = gpus; }
+  // gpak_phase_times of this model's context as one JSON object (the CLI's --timing)
+  std::string timingJson() const;
   bool Chol_failed() const { return Chol_fail; }
 
   void ToFile_GP_Params(std::ostream &out) const override;
@@ -131,6 +135,8 @@ class GP_utils : public Modeling, public Opt_Algs, public StreamIntfce {
  private:
   void sync_params() const;
   gpak_ctx *ctx = nullptr;
+  static int default_precision, default_gpus;
+  void create_ctx();
   bool owns_kernel = false;
   mutable bool dirty = true;     // KUpdateStat / AlphaUpStatus (GP_Utils.h:257-279)
   mutable bool Chol_fail = false;

@@ -58,6 +58,13 @@ typedef struct gpak_ctx gpak_ctx;
 /* ---- lifetime -------------------------------------------------------------------------- */
 /* device = HIP device ordinal. */
 int  gpak_create(gpak_ctx **out, int device, int precision);
+/* ONE process driving n_gpus devices (devices[r] = HIP ordinal of rank r; NULL = 0 .. n_gpus-1): the same gpak_ctx
+ * surface -- `gp_ss_ak --gpus n` runs on it.  logLikelihood / alpha run on the block-column-cyclic schedule of
+ * gpak_dist.h over all devices (RCCL panel broadcasts; an in-process peer-copy transport when RCCL cannot start or
+ * several ranks share a device); prediction is sharded over the test points with the factor replicated per device;
+ * gradient, Gram copies and solve_chol run on a replica of the model on devices[0].  3-D inputs, ExpAns(+Bias). */
+int  gpak_create_multi(gpak_ctx **out, int n_gpus, const int *devices, int precision);
+int  gpak_n_gpus(const gpak_ctx *ctx);
 void gpak_destroy(gpak_ctx *ctx);
 const char *gpak_last_error(const gpak_ctx *ctx);
 /* library-level error text for failures that happen before a ctx exists */
@@ -162,6 +169,13 @@ typedef struct {
   double gram_bytes;
   int    n;                  /* N                                                        */
   int    n_padded;           /* N rounded up to the 128-tile                             */
+  /* algorithmic HBM bytes of those trailing-update launches: every lower C tile read once and
+   * written once (2 x 128 x 128 x 8 B per tile), whatever the panel width K of the launch     */
+  double trailing_bytes;
+  double kmatvec_ms;         /* the fused Gram-matvec f = K alpha inside nlz_ms (fp64 VALU bound) */
+  double accumulated_ms[4];  /* gram / factor / solve / nlz summed over every evaluation since
+                                gpak_set_train, and ...                                          */
+  int    evaluations;        /* ... how many evaluations (factorisations) that was               */
 } gpak_phase_times;
 int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out);
 

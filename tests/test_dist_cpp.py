@@ -152,3 +152,104 @@ def test_bench_distributed_entry_point_with_several_ranks(world):
     assert all({"factor_ms", "bulk_ms", "chain_ms", "comm_ms", "wait_ms"} <= set(p) for p in d["phases_ms_per_rank"])
     s = _single(4096)
     assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
+
+
+# ---- ONE process driving several GPUs: gpak_create_multi (csrc/multi.hip) ---------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,n", [(1, 700), (2, 1500), (3, 2500), (4, 5000)])
+def test_multi_context_matches_oracle(orc, ranks, n):
+    """The gpak_ctx surface over a group of rank threads (here all on the box's one GPU, collectives through the
+    in-process peer-copy transport): nlZ / terms / alpha from the C++ block-column-cyclic schedule, prediction
+    sharded over the test points, gradient on the replica of device 0 -- all against the oracle, and repeated
+    with new parameters (buffers are reused between steps)."""
+    from gp_ss_ak_amd import gpak
+    E = np.array(synth.DEFAULT_EXPANS)
+    X, y = synth.drillholes(n)
+    Xt = synth.test_points(777)
+    g = gpak.Gpak(devices=[0] * ranks)
+    try:
+        g.set_train(X, y)
+        for k, sn2 in enumerate((synth.DEFAULT_SN2, 0.05)):
+            e = E.copy()
+            e[1] += 0.05 * k
+            g.set_params(e, synth.DEFAULT_BIAS, sn2, gpak.DIST_DIRECT)
+            K = orc.gram(X, X, e, synth.DEFAULT_BIAS, orc.DIST_DIRECT)
+            info, alpha, L = orc.nlz_refseq(K, y, sn2)
+            nlz = g.logLikelihood()
+            assert abs(nlz - info.nlz) <= 1e-9 * abs(info.nlz)
+            q, s, l = g.nlz_terms()
+            assert abs(l - info.logdet) <= 1e-10 * abs(info.logdet) and abs(q - info.quad) <= 1e-9 * abs(info.quad)
+            assert np.abs(g.solve_alpha() - alpha).max() <= 1e-8 * np.abs(alpha).max()
+            for compat in (0, 3):
+                mean, var = g.posteriorMeanVar(Xt, compat=compat)
+                mo, vo = orc.predict(X, Xt, e, synth.DEFAULT_BIAS, sn2, alpha, L, orc.DIST_DIRECT, compat)
+                assert np.abs(mean - mo).max() <= 1e-8 * np.abs(mo).max()
+                assert np.abs(var - vo).max() <= 1e-8 * np.abs(vo).max()
+            go = orc.grad_ref(X, y, K, L, alpha, e, synth.DEFAULT_BIAS, sn2, orc.DIST_DIRECT)
+            assert np.abs(g.GradLL() - go).max() <= 1e-8 * np.abs(go).max()
+        g.set_params(E, synth.DEFAULT_BIAS, -0.5, gpak.DIST_DIRECT)          # Chol_fail -> NaN on the group too
+        assert g.logLikelihood() != g.logLikelihood()
+    finally:
+        g.close()
+
+
+@pytest.mark.gpu
+def test_multi_context_expansion_mode_prediction_uses_the_pooled_mean_of_all_test_points(orc):
+    """Expansion-form distances are centred on the pooled mean of train + ALL test points (Kernel.cpp:1391-1392);
+    a sharded prediction must not centre every slice on its own mean."""
+    from gp_ss_ak_amd import gpak
+    E = np.array(synth.DEFAULT_EXPANS)
+    X, y = synth.drillholes(900)
+    Xt = synth.test_points(600)
+    one, many = gpak.Gpak(0), gpak.Gpak(devices=[0, 0, 0])
+    try:
+        for g in (one, many):
+            g.set_train(X, y)
+            g.set_params(E, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, gpak.DIST_EXPANSION)
+        m1, v1 = one.posteriorMeanVar(Xt)
+        m3, v3 = many.posteriorMeanVar(Xt)
+        assert abs(many.logLikelihood() - one.logLikelihood()) <= 1e-9 * abs(one.logLikelihood())
+        assert np.abs(m3 - m1).max() <= 1e-9 * np.abs(m1).max() and np.abs(v3 - v1).max() <= 1e-9 * np.abs(v1).max()
+    finally:
+        one.close()
+        many.close()
+
+
+@pytest.mark.gpu
+def test_cli_with_gpus_precision_and_timing(tmp_path):
+    """`gp_ss_ak --gpus 2 --precision f32 --timing -`: the device options of SURVEY.md section 5 through the train and
+    test verbs (two ranks rehearsed on the box's one GPU: GPAK_MULTI_DEVICES=0,0), same model as one GPU."""
+    host = os.path.join(ROOT, "gp_ss_ak_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host])
+    Xr, yr = synth.drillholes_raw(640)
+    perm = np.random.default_rng(5).permutation(640)
+    Xr, yr = Xr[perm], yr[perm]
+
+    def write(path, X, y):
+        with open(path, "w") as f:
+            for r, v in zip(X, y):
+                f.write("\t".join(f"{t:.17g}" for t in list(r) + [v]) + "\n")
+    write(tmp_path / "train.txt", Xr[:512], yr[:512])
+    write(tmp_path / "test.txt", Xr[512:], yr[512:])
+    exe = os.path.join(host, "gp_ss_ak")
+    runs = {}
+    for tag, opts, env in (("one", [], {}), ("two", ["--gpus", "2", "--precision", "f32"], {"GPAK_MULTI_DEVICES": "0,0"})):
+        model = str(tmp_path / f"model_{tag}")
+        e = dict(os.environ, GPAK_MAX_ITERS="4", **env)
+        out = subprocess.check_output([exe, "-v", "1", "-np"] + opts + ["--timing", "-", "train", "-k", "ExpAns", "-kn", "1",
+                                       "-o", "LBFGS", str(tmp_path / "train.txt"), model], env=e, cwd=tmp_path).decode()
+        its = [float(line.split("-logL:")[1]) for line in out.splitlines() if line.startswith("Iteration:")]
+        tim = json.loads([line for line in out.splitlines() if line.startswith("TIMING ")][0][7:])
+        out2 = subprocess.check_output([exe, "-v", "1", "-np"] + opts + ["--timing", str(tmp_path / f"t_{tag}.json"), "test",
+                                        str(tmp_path / "test.txt"), model, str(tmp_path / "train.txt")], env=e,
+                                       cwd=tmp_path).decode()
+        mse = float(out2.split("Mean Square Error of testing:")[1].split()[0])
+        tt = json.load(open(tmp_path / f"t_{tag}.json"))
+        runs[tag] = (its, tim, mse, tt)
+    assert runs["two"][1]["gpus"] == 2 and runs["two"][1]["precision"] == "f32" and runs["one"][1]["gpus"] == 1
+    assert runs["one"][1]["evaluations"] > 4 and runs["one"][1]["accumulated"]["factor_ms"] > 0
+    assert runs["one"][3]["last"]["predict_ms"] > 0
+    assert len(runs["one"][0]) == len(runs["two"][0]) >= 3
+    for a, b in zip(runs["one"][0][:2], runs["two"][0][:2]):      # six printed digits, before the optimiser's chaos
+        assert abs(a - b) <= 2e-5 * abs(a)
+    assert abs(runs["one"][2] - runs["two"][2]) <= 0.05 * runs["one"][2] + 1e-6
