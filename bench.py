@@ -101,6 +101,89 @@ def cpu_baseline(n_full, sample_n):
     }
 
 
+def _timed_steps(g, mode, steps, warmup):
+    """`steps` timed train steps after `warmup` untimed ones; returns (wall seconds, last nlZ, summed phases, launches)."""
+    def step(i):
+        e, bias, sn2 = params_for_step(i)
+        g.set_params(e, bias, sn2, mode)
+        return g.logLikelihood()
+
+    for i in range(warmup):
+        step(i)
+    keys = ("gram_ms", "factor_ms", "solve_ms", "nlz_ms", "kmatvec_ms", "trailing_ms", "trailing_flops", "trailing_bytes")
+    phases = {k: 0.0 for k in keys}
+    launches = 0
+    t0 = time.perf_counter()
+    nlz = None
+    for i in range(steps):
+        nlz = step(warmup + i)  # synchronous: returns after the device finished
+        t = g.timing()
+        for k in keys:
+            phases[k] += t[k]
+        launches += t["trailing_launches"]
+    return time.perf_counter() - t0, nlz, phases, launches
+
+
+def _pmc(tag, N):
+    """HBM-side traffic and in-situ clock of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
+    command (profiles/<tag>_pmc_summary_N<N>.json, written by tools/profile_round.sh <tag>): per launch,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary_N{N}.json")
+    if not os.path.exists(path):
+        return None
+    z = json.load(open(path))
+    k = "void gpak_gemm_nt_f64_rs<4, 2, true>"
+    out = {"source": os.path.relpath(path, ROOT)}
+    try:
+        f, w = z["FETCH_SIZE"][k]["FETCH_SIZE"], z["WRITE_SIZE"][k]["WRITE_SIZE"]
+        out["traffic"] = (2.0 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024.0
+    except KeyError:
+        out["traffic"] = None
+    try:
+        sq = z["SQ"][k]
+        out["mfma_busy_cycles_per_launch"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / sq["SQ_VALU_MFMA_BUSY_CYCLES"]["dispatches"]
+        out["grbm_gui_active_per_launch"] = sq["GRBM_GUI_ACTIVE"]["sum"] / sq["GRBM_GUI_ACTIVE"]["dispatches"]
+    except KeyError:
+        pass
+    return out
+
+
+def config3(iters, N=32768):
+    """BASELINE.json configs[2]: the full L-BFGS hyper-parameter loop through the C++ CLI (per-evaluation Gram rebuild
+    + Cholesky; gradient evaluations add the B^-1 build).  Returns ms per iteration and evaluations per iteration."""
+    import subprocess
+    import tempfile
+    from gp_ss_ak_amd import synth
+    exe = os.path.join(ROOT, "gp_ss_ak_amd", "host", "gp_ss_ak")
+    if not os.path.exists(exe):
+        return {"error": "gp_ss_ak_amd/host/gp_ss_ak is not built"}
+    with tempfile.TemporaryDirectory() as d:
+        Xr, yr = synth.drillholes_raw(N)
+        with open(os.path.join(d, "train.txt"), "w") as f:
+            for r, v in zip(Xr, yr):
+                f.write("\t".join(f"{t:.17g}" for t in list(r) + [v]) + "\n")
+        env = dict(os.environ, GPAK_MAX_ITERS=str(iters), GPAK_OPT_TRACE=os.path.join(d, "trace.txt"))
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, "-v", "1", "-np", "--timing", os.path.join(d, "timing.json"), "train", "-k", "ExpAns",
+                              "-kn", "1", "-o", "LBFGS", os.path.join(d, "train.txt"), os.path.join(d, "model")],
+                             env=env, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        if out.returncode != 0:
+            return {"error": out.stderr.decode()[-500:]}
+        rows = [[float(v) for v in line.split()] for line in open(os.path.join(d, "trace.txt"))]
+        tim = json.load(open(os.path.join(d, "timing.json")))
+    evals = int(rows[-1][2])
+    acc = tim["accumulated"]
+    dev_ms = acc["gram_ms"] + acc["factor_ms"] + acc["solve_ms"] + acc["nlz_ms"]
+    return {"N": N, "iterations": len(rows), "evaluations": evals, "evaluations_per_iteration": evals / len(rows),
+            "kept_objective": [r[1] for r in rows], "train_verb_wall_s": wall,
+            "hot_path_evaluations": tim["evaluations"], "hot_path_ms_per_evaluation": dev_ms / max(tim["evaluations"], 1),
+            "last_grad_ms": tim["last"]["grad_ms"],
+            "note": "train verb end to end (csv read, L-BFGS, model file, Calc_Out on the N training points); every "
+                    "evaluation is a new parameter vector: fill + Cholesky + solves + nlZ, gradient evaluations add "
+                    "B^-1 (2N^3/3) + the fused pair pass"}
+
+
 def run_single(args):
     from gp_ss_ak_amd import gpak, synth
     N = args.n
@@ -111,30 +194,19 @@ def run_single(args):
         g.set_option(gpak.OPT_NB_OUTER, args.nb_outer)
     g.set_train(X, y)  # inputs resident in HBM from here on
     mode = gpak.DIST_DIRECT if args.dist == "direct" else gpak.DIST_EXPANSION
-
-    def step(i):
-        e, bias, sn2 = params_for_step(i)
-        g.set_params(e, bias, sn2, mode)
-        return g.logLikelihood()
-
-    for i in range(args.warmup):
-        step(i)
-    phases = {k: 0.0 for k in ("gram_ms", "factor_ms", "solve_ms", "nlz_ms", "trailing_ms", "trailing_flops")}
-    launches = 0
-    t0 = time.perf_counter()
-    nlz = None
-    for i in range(args.steps):
-        nlz = step(args.warmup + i)  # synchronous: returns after the device finished
-        t = g.timing()
-        for k in phases:
-            phases[k] += t[k]
-        launches += t["trailing_launches"]
-    wall = time.perf_counter() - t0
+    wall, nlz, phases, launches = _timed_steps(g, mode, args.steps, args.warmup)
     ms_per_step = wall / args.steps * 1e3
     achieved = phases["trailing_flops"] / (phases["trailing_ms"] * 1e-3) / 1e12 if phases["trailing_ms"] > 0 else None
     tim = g.timing()
+    Np = tim["n_padded"]
+    fill_gbs = tim["gram_bytes"] / (phases["gram_ms"] / args.steps * 1e-3) / 1e9
+    # fp64 vector rate: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s; one kernel evaluation
+    # of the default composition is 32 fp64 instruction slots (6 distance, 13 sqrt incl. v_rsq_f64 at quarter rate,
+    # 12 exp, 1 accumulate: csrc/gram.hip gpak_k1)
+    kmv_s = phases["kmatvec_ms"] / args.steps * 1e-3
+    kmv_rate = float(N) * N * 32.0 / kmv_s if kmv_s > 0 else None
     out = {
-        "metric": "GP train step/sec (Gram+Cholesky+logML) at N=32768 fp64",
+        "metric": f"GP train step/sec (Gram+Cholesky+logML) at N={N} fp64",
         "value": args.steps / wall,
         "unit": "steps/s",
         "n_gpus": 1,
@@ -149,7 +221,7 @@ def run_single(args):
         "config": {"workload": f"N={N} fp64 ExpAns+Bias Gram + blocked Cholesky + 2 trsv + logML, 3-D synthetic "
                                f"drill-holes, new hyper-parameters every step", "N": N, "dist_mode": args.dist,
                    "nb_outer": args.nb_outer or 512, "parallelism": "1 GPU"},
-        "phases_ms_per_step": {k: phases[k] / args.steps for k in ("gram_ms", "factor_ms", "solve_ms", "nlz_ms")},
+        "phases_ms_per_step": {k: phases[k] / args.steps for k in ("gram_ms", "factor_ms", "solve_ms", "nlz_ms", "kmatvec_ms")},
         "nlz": nlz,
         "roofline": {
             "kernel": "gpak_gemm_nt_f64_rs (Cholesky trailing update, v_mfma_f64_16x16x4_f64, register-streamed operands)",
@@ -159,15 +231,35 @@ def run_single(args):
             "unit": "TFLOP/s",
             "frac": (achieved / PEAK_F64_MFMA_TFLOPS) if achieved else None,
             "traffic": None,
-            "algorithmic_bytes_per_launch": (phases["trailing_flops"] / (2.0 * 128 * 128 * (args.nb_outer or 512))
-                                             * 2 * 128 * 128 * 8) / max(launches, 1),
+            # every lower C tile read once and written once per launch, whatever the launch's panel width K
+            "algorithmic_bytes_per_launch": phases["trailing_bytes"] / max(launches, 1),
             "avg_launch_ms": phases["trailing_ms"] / max(launches, 1),
             "launches_per_step": launches / args.steps,
             "flops_per_step": phases["trailing_flops"] / args.steps,
-            "whole_factor_frac": ((tim["n_padded"] ** 3 / 3.0) / (phases["factor_ms"] / args.steps * 1e-3) / 1e12
+            "whole_factor_frac": ((Np ** 3 / 3.0) / (phases["factor_ms"] / args.steps * 1e-3) / 1e12
                                   / PEAK_F64_MFMA_TFLOPS),
+            "fill": {"kernel": "gpak_fill1_f64 (fused Gram/B fill, lower 128x64 tiles)", "bound": "hbm",
+                     "achieved": fill_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": fill_gbs / PEAK_HBM_GBS,
+                     "algorithmic_bytes": tim["gram_bytes"], "ms": phases["gram_ms"] / args.steps},
+            "kmatvec": {"kernel": "gpak_kmatvec1_part_f64 (f = K alpha, K recomputed, nothing stored)", "bound": "valu_f64",
+                        "achieved": kmv_rate / 1e12 if kmv_rate else None, "peak": 39.3, "unit": "T lane-instr/s",
+                        "frac": kmv_rate / 39.3e12 if kmv_rate else None, "evaluations": float(N) * N,
+                        "fp64_instructions_per_evaluation": 32, "ms": kmv_s * 1e3},
         },
     }
+    tag = args.profile_tag
+    out["profile_tag"] = tag
+    pm = _pmc(tag, N)
+    if pm is not None:
+        out["roofline"]["traffic"] = pm.get("traffic")
+        out["roofline"]["traffic_source"] = pm["source"] + " (2*FETCH_SIZE + WRITE_SIZE per launch)"
+        if "grbm_gui_active_per_launch" in pm and out["roofline"]["avg_launch_ms"]:
+            # GRBM_GUI_ACTIVE counts per XCD; the collected value is the sum over the 8 XCDs
+            ghz = pm["grbm_gui_active_per_launch"] / 8.0 / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+            out["roofline"]["in_situ_clock_ghz"] = ghz
+            out["roofline"]["peak_at_in_situ_clock"] = PEAK_F64_MFMA_TFLOPS * ghz / 2.4
+            out["roofline"]["mfma_busy_frac"] = (pm["mfma_busy_cycles_per_launch"] / (256 * 4) /
+                                                 (pm["grbm_gui_active_per_launch"] / 8.0))
     if args.grad:
         # config 3 of BASELINE.json: what one Grad_Values() of the L-BFGS loop costs on top of ObjVal()
         t0 = time.perf_counter()
@@ -178,24 +270,26 @@ def run_single(args):
         gwall = (time.perf_counter() - t0) / args.grad
         tg = g.timing()
         out["grad_step"] = {"ms_per_grad_eval": gwall * 1e3, "grad_ms": tg["grad_ms"],
-                            "algorithmic_flops": 2.0 * tim["n_padded"] ** 3 / 3.0,
-                            "tflops": 2.0 * tim["n_padded"] ** 3 / 3.0 / (tg["grad_ms"] * 1e-3) / 1e12,
+                            "algorithmic_flops": 2.0 * Np ** 3 / 3.0,
+                            "tflops": 2.0 * Np ** 3 / 3.0 / (tg["grad_ms"] * 1e-3) / 1e12,
                             "g": [float(v) for v in gv]}
-    pmc = os.path.join(ROOT, "profiles", "r01_j_pmc_summary_N32768.json")
-    if N == 32768 and os.path.exists(pmc):
-        # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes (separate runs of
-        # this command): per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads
-        z = json.load(open(pmc))
-        k = "void gpak_gemm_nt_f64_rs<4, 2, true>"
-        f, w = z["FETCH_SIZE"][k]["FETCH_SIZE"], z["WRITE_SIZE"][k]["WRITE_SIZE"]
-        out["roofline"]["traffic"] = (2.0 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024.0
-        out["roofline"]["traffic_source"] = "profiles/r01_j_pmc_summary_N32768.json (2*FETCH_SIZE + WRITE_SIZE per launch)"
     if args.calibrate:
         tf, gbs = g.calibrate()
         out["roofline"]["calibrated_mfma_f64_tflops"] = tf
         out["roofline"]["calibrated_hbm_write_gbs"] = gbs
-        out["roofline"]["gram_fill_gbs"] = tim["gram_bytes"] / (phases["gram_ms"] / args.steps * 1e-3) / 1e9
+        out["roofline"]["fill"]["calibrated_store_gbs"] = gbs
+        out["roofline"]["fill"]["frac_of_calibrated"] = fill_gbs / gbs
+    if N != 65536 and not args.no_n65536:
+        # north_star's scaling curve is quoted at N=65536 (BASELINE.json configs[3]): the 1-GPU point (34 GB matrix)
+        X6, y6 = synth.drillholes(65536)
+        g.set_train(X6, y6)
+        w6, nlz6, ph6, _ = _timed_steps(g, mode, 2, 1)
+        out["n65536"] = {"N": 65536, "steps_per_s": 2 / w6, "ms_per_step": w6 / 2 * 1e3, "nlz": nlz6,
+                         "factor_ms": ph6["factor_ms"] / 2,
+                         "whole_factor_frac": (65536 ** 3 / 3.0) / (ph6["factor_ms"] / 2 * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
     g.close()
+    if args.config3 and N == 32768:
+        out["config3"] = config3(args.config3, N)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(N, args.cpu_n)
     return out
@@ -210,11 +304,15 @@ def main():
     ap.add_argument("--n", "--size", dest="n", type=int, default=32768)
     ap.add_argument("--dist", choices=["direct", "expansion"], default="direct")
     ap.add_argument("--nb-outer", type=int, default=0)
-    ap.add_argument("--cpu-n", type=int, default=12288, help="sample size of the CPU baseline (~10 s of CPU work)")
+    ap.add_argument("--cpu-n", type=int, default=16384, help="sample size of the CPU baseline (~15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--grad", type=int, default=0, help="also time this many GradLL evaluations (config 3)")
     ap.add_argument("--calibrate", action="store_true", default=True)
     ap.add_argument("--no-n65536", action="store_true", help="skip the N=65536 sub-run (north_star's scaling size)")
+    ap.add_argument("--config3", type=int, default=2, help="L-BFGS iterations of the configs[2] sub-run through the CLI "
+                                                            "(N=32768 only; 0 = skip)")
+    ap.add_argument("--profile-tag", default=os.environ.get("GPAK_PROFILE_TAG", "r02"),
+                    help="profiles/<tag>_pmc_summary_N<N>.json supplies `traffic` and the in-situ clock")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("GPAK_FORCE_DIST"):

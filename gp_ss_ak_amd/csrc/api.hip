@@ -133,7 +133,8 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
   if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&ctx->stream_hi, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
-      (e = hipStreamCreateWithPriority(&ctx->stream_fs, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
+      (e = hipStreamCreateWithPriority(&ctx->stream_fs, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&ctx->stream_x, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
     g_global_err = hipGetErrorString(e); delete ctx; return GPAK_EHIP;
   }
   // a copy of the main stream that may not use the first GPAK_TAIL_MASK (default 8) compute units; the bulk
@@ -190,6 +191,7 @@ void gpak_destroy(gpak_ctx *ctx) {
   for (auto e : ctx->ev_sync) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream_hi);
   hipStreamDestroy(ctx->stream_fs);
+  hipStreamDestroy(ctx->stream_x);
   if (ctx->stream_tail) hipStreamDestroy(ctx->stream_tail);
   hipStreamDestroy(ctx->stream);
   delete ctx;

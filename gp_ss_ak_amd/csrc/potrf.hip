@@ -315,6 +315,42 @@ static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W) {
   gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false);
 }
 
+// Chain-bound tail: the same panel factorisation (W <= 512), but the update of the NEXT block column [J1, J2) is
+// applied sub-panel by sub-panel (K = 128) on a side stream `sx` as soon as each 128-column sub-panel is solved,
+// instead of as one K = W product on the panel stream after the whole panel: the next panel's first potrf128 then
+// waits for one K = 128 product (~15 us) instead of a K = 512 one (~52 us).  `first_wait` (the previous bulk update,
+// which touched [J1, J2)) is waited for once on sx; `done` is recorded on sx behind the last sub-update.
+static int factor_panel_tail(gpak_ctx *ctx, hipStream_t sp, hipStream_t sx, int J, int W, int J1, int J2,
+                             hipEvent_t first_wait, hipEvent_t *evs, hipEvent_t done) {
+  const long ld = ctx->ld;
+  double *M = ctx->dM;
+  const int Np = ctx->Np;
+  if (first_wait) GPAK_HIP(hipStreamWaitEvent(sx, first_wait, 0));
+  int k = 0;
+  for (int j = J; j < J + W; j += PB, k++) {
+    double *inv = ctx->dInv + (size_t)(j / PB) * 2 * PB * PB;
+    gpak_launch_potrf128(sp, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo, false);
+    const int mt = (Np - j - PB) / PB;
+    if (mt <= 0) continue;
+    double *P = M + (j + PB) + (size_t)j * ld;
+    gpak_launch_gemm_nt(sp, mt, 1, PB, 1.0, P, ld, inv, PB, 0.0, P, ld, 0, 0, false, false);
+    GPAK_HIP(hipEventRecord(evs[k], sp));
+    const int nct = (J + W - (j + PB)) / PB;
+    if (nct > 0)
+      gpak_launch_gemm_nt(sp, mt, nct, PB, -1.0, P, ld, P, ld, 1.0, M + (j + PB) + (size_t)(j + PB) * ld, ld, 0, 0, true,
+                          false);
+    // next block column: rows >= J1 of sub-panel j against its rows [J1, J2)
+    const int mt2 = (Np - J1) / PB, nt2 = (J2 - J1) / PB;
+    if (mt2 > 0 && nt2 > 0) {
+      GPAK_HIP(hipStreamWaitEvent(sx, evs[k], 0));
+      const double *P1 = M + J1 + (size_t)j * ld;
+      gpak_launch_gemm_nt(sx, mt2, nt2, PB, -1.0, P1, ld, P1, ld, 1.0, M + J1 + (size_t)J1 * ld, ld, 0, 0, true, false);
+    }
+  }
+  GPAK_HIP(hipEventRecord(done, sx));
+  return GPAK_OK;
+}
+
 // Update of the columns [c0, c1) (and all rows >= c0) with the factored panel [J, J+W).
 static void update_cols(gpak_ctx *ctx, hipStream_t st, int J, int W, int c0, int c1, bool trailing) {
   const long ld = ctx->ld;
@@ -348,16 +384,19 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   static const int nb_wide = getenv("GPAK_NB_WIDE") ? atoi(getenv("GPAK_NB_WIDE")) / PB * PB : 1024;   // 0: off
   static const int nb_wide_rows = getenv("GPAK_NB_WIDE_ROWS") ? atoi(getenv("GPAK_NB_WIDE_ROWS")) : 20480;
   std::vector<int> Js;
+  // the very first panel has nothing to hide behind: keep it narrow so that the first bulk update starts early
+  // (measured at N=32768: 183.07 -> 183.34 ms, i.e. nothing: off unless GPAK_FIRST_NARROW=1)
+  static const bool first_narrow = getenv("GPAK_FIRST_NARROW") && atoi(getenv("GPAK_FIRST_NARROW")) != 0;
   for (int J = 0; J < Np;) {
     Js.push_back(J);
-    J += (nb_wide > NB && Np - J > nb_wide_rows) ? nb_wide : NB;
+    J += (nb_wide > NB && Np - J > nb_wide_rows && !(first_narrow && J == 0)) ? nb_wide : NB;
   }
   const int nJ = (int)Js.size();
   Js.push_back(Np);
   const int init = 0x7fffffff;
   GPAK_HIP(hipMemcpyAsync(ctx->dInfo, &init, sizeof(int), hipMemcpyHostToDevice, su));
 
-  while ((int)ctx->ev_sync.size() < 2 * nJ + 4) {
+  while ((int)ctx->ev_sync.size() < 2 * nJ + 4 + 5) {
     hipEvent_t e;
     GPAK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->ev_sync.push_back(e);
@@ -365,6 +404,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   hipEvent_t *EF = ctx->ev_sync.data(), *EU = ctx->ev_sync.data() + nJ;
   hipEvent_t Estart = ctx->ev_sync[2 * nJ], Eend = ctx->ev_sync[2 * nJ + 1], Efs = ctx->ev_sync[2 * nJ + 2];
   hipEvent_t Eorder = ctx->ev_sync[2 * nJ + 3];
+  hipEvent_t *EX = ctx->ev_sync.data() + 2 * nJ + 4, EXdone = ctx->ev_sync[2 * nJ + 8];
   // the panel stream starts after everything queued so far on the main stream (the fill)
   GPAK_HIP(hipEventRecord(Estart, su));
   GPAK_HIP(hipStreamWaitEvent(sp, Estart, 0));
@@ -373,9 +413,24 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   int done512 = 0;
   double tflops = 0.0, tbytes = 0.0;
   int tl = 0;
+  static const int tail_rows = getenv("GPAK_TAIL_ROWS") ? atoi(getenv("GPAK_TAIL_ROWS")) : 12288;
+  // sub-panel updates of the next block column in the tail (factor_panel_tail): measured 183.07 -> 183.73 ms at
+  // N=32768 -- the four K=128 products re-read and re-write the column four times and the chain gains nothing
+  // measurable; off unless GPAK_SUB_NEXT=1 (kept: the multi-GPU schedule is built the same way and tests compare)
+  static const bool sub_next = getenv("GPAK_SUB_NEXT") && atoi(getenv("GPAK_SUB_NEXT")) != 0;
+  bool next_col_done = false;   // the next block column already has this panel's update (applied per sub-panel)
   for (int b = 0; b < nJ; b++) {
     const int J = Js[b], W = Js[b + 1] - J;
-    factor_panel(ctx, sp, J, W);
+    const int J1n = J + W, J2n = J1n < Np ? Js[b + 2] : Np;
+    const bool tail_step = sub_next && ctx->lookahead && ctx->stream_x && W <= 512 && J1n < Np && Np - J1n <= tail_rows;
+    if (tail_step) {
+      int rc = factor_panel_tail(ctx, sp, ctx->stream_x, J, W, J1n, J2n, b > 0 ? EU[b - 1] : nullptr, EX, EXdone);
+      if (rc) return rc;
+      next_col_done = true;
+    } else {
+      factor_panel(ctx, sp, J, W);
+      next_col_done = false;
+    }
     GPAK_HIP(hipEventRecord(EF[b], sp));
     // forward substitution of the right-hand side y/sn2 rides along: block column b of L is final
     // here and the solve touches only the two work vectors.  It has its own stream so that its four
@@ -397,12 +452,15 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
     if (J1 >= Np) break;
     const int J2 = Js[b + 2];
     // next panel's columns first, on the panel stream (after the previous bulk update)
-    if (b > 0) GPAK_HIP(hipStreamWaitEvent(sp, EU[b - 1], 0));
-    update_cols(ctx, sp, J, W, J1, J2, false);
+    if (next_col_done) {
+      GPAK_HIP(hipStreamWaitEvent(sp, EXdone, 0));
+    } else {
+      if (b > 0) GPAK_HIP(hipStreamWaitEvent(sp, EU[b - 1], 0));
+      update_cols(ctx, sp, J, W, J1, J2, false);
+    }
     if (J2 < Np) {
       // chain-bound tail: the bulk update is off the critical path there; on the CU-masked stream it leaves
       // idle compute units to potrf128 and the small panel products
-      static const int tail_rows = getenv("GPAK_TAIL_ROWS") ? atoi(getenv("GPAK_TAIL_ROWS")) : 12288;
       hipStream_t su_b = (ctx->stream_tail && ctx->lookahead && Np - J2 <= tail_rows) ? ctx->stream_tail : ctx->stream;
       if (su_b != su) {                       // keep the order of successive bulk updates across the two streams
         GPAK_HIP(hipEventRecord(Eorder, su));

@@ -161,6 +161,22 @@ def test_cli_train_then_test_config1(tmp_path):
     assert os.path.exists(model) and os.path.exists(model + "_Statistics.txt")
     txt = open(model).read().splitlines()
     assert txt[0].startswith("# GP_SS_AK Model File") and txt[1] == "Inference=Lapalce" and "KernelName=Hyb" in txt
+    # the full key order of the text model (GP_Utils.cpp:1360-1390 ToFile_GP_Params, Kernel.cpp:20-75 / 1281-1338
+    # StrmOut): a value-only line follows each child's numParams
+    keys = [line.split("=")[0] for line in txt[1:] if "=" in line]
+    assert keys == ["Inference", "likelihood", "MeanFunction", "numData", "outputDim", "inputDim", "NumHyperKernel",
+                    "NumHyperLik", "NumHyperMean", "KernelName", "NumberOfKernels",
+                    "KernelName", "inputDim", "numParams", "KernelName", "inputDim", "numParams",
+                    "Hyperparams_likelihood"]
+    body = txt[1:]
+    kv = dict(line.split("=", 1) for line in body if "=" in line)
+    assert kv["numData"] == "512" and kv["outputDim"] == "1" and kv["NumHyperKernel"] == "9" and kv["NumHyperLik"] == "1"
+    assert kv["NumHyperMean"] == "0" and kv["NumberOfKernels"] == "2"
+    names = [line.split("=")[1] for line in body if line.startswith("KernelName=")]
+    assert names == ["Hyb", "ExpAns", "Bias"]
+    value_lines = [line for line in body if "=" not in line and line.strip()]
+    assert len(value_lines) == 2 and len(value_lines[0].split()) == 8 and len(value_lines[1].split()) == 1
+    assert all(len(v.replace("-", "").replace(".", "").lstrip("0")) <= 6 or "e" in v for v in value_lines[0].split())  # Q5
     mse_train = float(out.split("Mean Square Error of training:")[1].split()[0])
     out2 = subprocess.check_output([exe, "-v", "1", "-np", "test", str(tmp_path / "test.txt"), model,
                                     str(tmp_path / "train.txt")], cwd=tmp_path).decode()
