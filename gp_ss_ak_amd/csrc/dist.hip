@@ -609,6 +609,24 @@ static int produce(gpak_dist *h, int b, void **done) {
   return GPAK_OK;
 }
 
+// Every collective of a rank goes through ONE stream (the communication stream) in one global issue order: RCCL
+// serialises the operations of a communicator, and two streams feeding the same communicator concurrently is the
+// classic way to deadlock it.  `hop_in` orders the communication stream behind the bulk stream, `hop_out` back.
+static int hop_in(gpak_dist *h) {
+  if (h->s_comm == h->s_bulk) return GPAK_OK;
+  void *e = h->sync_event();
+  DCHK(h->E.event_record(h->E.self, e, h->s_bulk));
+  DCHK(h->E.stream_wait_event(h->E.self, h->s_comm, e));
+  return GPAK_OK;
+}
+static int hop_out(gpak_dist *h) {
+  if (h->s_comm == h->s_bulk) return GPAK_OK;
+  void *e = h->sync_event();
+  DCHK(h->E.event_record(h->E.self, e, h->s_comm));
+  DCHK(h->E.stream_wait_event(h->E.self, h->s_bulk, e));
+  return GPAK_OK;
+}
+
 static int factor(gpak_dist *h, int *failed_col) {
   gpak_dist_engine &E = h->E;
   gpak_dist_transport &T = h->T;
@@ -675,7 +693,9 @@ static int factor(gpak_dist *h, int *failed_col) {
   void *e_aux = h->sync_event();
   DCHK(E.event_record(E.self, e_aux, h->s_aux));
   DCHK(E.stream_wait_event(E.self, h->s_bulk, e_aux));
-  DCHK(T.allreduce_min_int(T.self, h->s_bulk, h->info, 1));
+  DCHK(hop_in(h));
+  DCHK(T.allreduce_min_int(T.self, h->s_comm, h->info, 1));
+  DCHK(hop_out(h));
   int info = init;
   DCHK(E.download(E.self, h->s_bulk, &info, h->info, sizeof(int)));
   *failed_col = info == init ? 0 : info;
@@ -741,14 +761,18 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   DCHK(E.zero(E.self, h->s_bulk, h->f, sizeof(double) * Np));
   if (i1 > i0)
     DCHK(E.kmatvec(h->s_bulk, h->u, h->cap, N, i0, i1, h->alpha, h->expans, h->bias, h->mode, h->scratch, h->f));
-  DCHK(T.allreduce_sum(T.self, h->s_bulk, h->f, (size_t)Np));
+  DCHK(hop_in(h));
+  DCHK(T.allreduce_sum(T.self, h->s_comm, h->f, (size_t)Np));
+  DCHK(hop_out(h));
   for (size_t i = 0; i < h->owned.size(); i++) {
     const int b = h->owned[i];
     DCHK(E.logdiag_block(h->s_bulk, h->blk(b), h->ld, h->start(b), h->width(b), N, h->ld_slots + i));
   }
   DCHK(E.zero(E.self, h->s_bulk, h->small, sizeof(double) * 16));
   if (!h->owned.empty()) DCHK(E.vec_sum(h->s_bulk, (int)h->owned.size(), h->ld_slots, h->small + 2));
-  DCHK(T.allreduce_sum(T.self, h->s_bulk, h->small + 2, 1));
+  DCHK(hop_in(h));
+  DCHK(T.allreduce_sum(T.self, h->s_comm, h->small + 2, 1));
+  DCHK(hop_out(h));
   DCHK(E.nlz_terms(h->s_bulk, N, h->y, h->f, h->alpha, h->sn2, h->small));
   tp[4] = h->time_event(h->s_bulk);
   double vals[3];

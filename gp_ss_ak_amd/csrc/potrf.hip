@@ -382,11 +382,11 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   // panel keeps the chain short (N=32768: 180.8 -> 178.5 ms).  GPAK_NB_WIDE / GPAK_NB_WIDE_ROWS: width and
   // "rows left" threshold; only applies when nb_outer is narrower than the wide width.
   static const int nb_wide = getenv("GPAK_NB_WIDE") ? atoi(getenv("GPAK_NB_WIDE")) / PB * PB : 1024;   // 0: off
-  static const int nb_wide_rows = getenv("GPAK_NB_WIDE_ROWS") ? atoi(getenv("GPAK_NB_WIDE_ROWS")) : 20480;
+  static const int nb_wide_rows = getenv("GPAK_NB_WIDE_ROWS") ? atoi(getenv("GPAK_NB_WIDE_ROWS")) : 16384;
   std::vector<int> Js;
   // the very first panel has nothing to hide behind: keep it narrow so that the first bulk update starts early
-  // (measured at N=32768: 183.07 -> 183.34 ms, i.e. nothing: off unless GPAK_FIRST_NARROW=1)
-  static const bool first_narrow = getenv("GPAK_FIRST_NARROW") && atoi(getenv("GPAK_FIRST_NARROW")) != 0;
+  // (measured at N=32768, 30-step A/B inside one box: 182.46 -> 181.90 ms)
+  static const bool first_narrow = !(getenv("GPAK_FIRST_NARROW") && atoi(getenv("GPAK_FIRST_NARROW")) == 0);
   for (int J = 0; J < Np;) {
     Js.push_back(J);
     J += (nb_wide > NB && Np - J > nb_wide_rows && !(first_narrow && J == 0)) ? nb_wide : NB;
