@@ -626,7 +626,7 @@ def bench(args):
     if rank == 0:
         flops = gp.Np ** 3 / 3.0
         out = {
-            "metric": "GP train step/sec (Gram+Cholesky+logML) at N=32768 fp64",
+            "metric": f"GP train step/sec (Gram+Cholesky+logML) at N={N} fp64",
             "value": args.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -92,7 +92,16 @@ def one(N, modes=("direct", "expansion")):
     for name in modes:
         mode = orc.DIST_DIRECT if name == "direct" else orc.DIST_EXPANSION
         t0 = time.time()
-        B = orc.gram(X, X, E, BIAS, mode)            # F-ordered N x N
+        if N <= 32768:
+            B = orc.gram(X, X, E, BIAS, mode)        # F-ordered N x N
+        else:
+            # the oracle's Gram keeps a second N x N array (D2): beyond N = 32768 that does not fit beside B in
+            # 62 GB, so B is assembled from 4096-column slabs (direct mode: the same numbers up to the rounding of
+            # the centring, which differs per slab; the expansion form is not generated at this size)
+            B = np.empty((N, N), order="F")
+            for j0 in range(0, N, 4096):
+                j1 = min(N, j0 + 4096)
+                B[:, j0:j1] = orc.gram(X, np.asfortranarray(X[j0:j1]), E, BIAS, mode)
         B *= 1.0 / SN2
         B[np.diag_indices(N)] += 1.0
         t1 = time.time()
@@ -128,4 +137,4 @@ def one(N, modes=("direct", "expansion")):
 
 if __name__ == "__main__":
     for n in [int(a) for a in sys.argv[1:]] or [8192]:
-        one(n)
+        one(n, modes=("direct", "expansion") if n <= 32768 else ("direct",))

@@ -1,4 +1,5 @@
-"""The N>1 path: gp_ss_ak_amd.multigpu.DistGP under torch.distributed.
+"""The round-1 Python schedule gp_ss_ak_amd.multigpu.DistGP under torch.distributed -- kept as a second, independent
+implementation of the multi-GPU schedule (the product path is the C++ one: tests/test_dist_cpp.py).
 
 CPU (-m "not gpu"): world_size 2 and 3 over gloo with the NumPy stand-in engine -- checks the
 block-column-cyclic ownership, the look-ahead schedule, the panel broadcast and the solve
@@ -108,7 +109,7 @@ def test_bench_distributed_entry_point_over_rccl():
     """bench.py --gpus path exactly as the driver launches it (torch.distributed.run, backend nccl = RCCL),
     with the one rank this box has; the step must agree with the single-context path."""
     root = os.path.dirname(HERE)
-    env = dict(os.environ, GPAK_FORCE_DIST="1")
+    env = dict(os.environ, GPAK_FORCE_DIST="1", GPAK_DIST_IMPL="python")   # the round-1 Python schedule (test harness)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps",
            "2", "--warmup", "1", "--size", "4096", "--no-cpu"]
@@ -130,7 +131,7 @@ def test_bench_distributed_entry_point_with_several_ranks(world):
     """bench.py --gpus N as the driver launches it, N ranks rehearsed on this box's one GPU over gloo
     (sub-panel pipeline on, RCCL replaced by gloo): same nlZ as the single-context path, one JSON line."""
     root = os.path.dirname(HERE)
-    env = dict(os.environ, GPAK_DIST_BACKEND="gloo", GPAK_DIST_DEVICE="0")
+    env = dict(os.environ, GPAK_DIST_BACKEND="gloo", GPAK_DIST_DEVICE="0", GPAK_DIST_IMPL="python")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
            "--steps", "2", "--warmup", "1", "--size", "4096", "--no-cpu"]
