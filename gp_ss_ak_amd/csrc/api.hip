@@ -22,6 +22,7 @@ int gpak_multi_nlz(gpak_multi *g, double *nlz, double *quad, double *sumlp, doub
 int gpak_multi_alpha(gpak_multi *g, double *alpha_host);
 int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f);
 int gpak_multi_predict(gpak_multi *g, const double *Xte, long M, int d, double *mean, double *var);
+int gpak_multi_grad(gpak_multi *g, double *grad10);
 int gpak_multi_timing(gpak_multi *g, gpak_phase_times *out);
 int gpak_multi_n(gpak_multi *g);
 #define GPAK_MULTI_ERR(rc_) do { int v_ = (rc_); if (v_) ctx->err = gpak_multi_error(ctx->multi); return v_; } while (0)
@@ -633,7 +634,7 @@ int gpak_predict(gpak_ctx *ctx, const double *Xte, long M, int d, double *mean, 
 
 int gpak_grad(gpak_ctx *ctx, double *g) {
   if (!ctx || !g) return GPAK_EINVAL;
-  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_grad(c, g); }));
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_grad(ctx->multi, g));
   if (!ctx->expans_only) { ctx->err = "gpak_grad handles the ExpAns(+Bias) composition only"; return GPAK_ENOTIMPL; }
   int rc = ensure_nlz(ctx);  // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
   if (rc) return rc;
@@ -642,7 +643,10 @@ int gpak_grad(gpak_ctx *ctx, double *g) {
 
 int gpak_grad_hyb(gpak_ctx *ctx, double *g, int ng) {
   if (!ctx || !g) return GPAK_EINVAL;
-  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_grad_hyb(c, g, ng); }));
+  if (ctx->multi) {
+    if (ng != 10) { ctx->err = "a multi-GPU context handles the ExpAns(+Bias) composition: ng must be 10"; return GPAK_EINVAL; }
+    GPAK_MULTI_ERR(gpak_multi_grad(ctx->multi, g));
+  }
   int rc = ensure_nlz(ctx);
   if (rc) return rc;
   return gpak_grad_impl(ctx, g, ng);

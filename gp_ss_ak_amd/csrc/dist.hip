@@ -132,6 +132,8 @@ void fill_hip_engine(gpak_dist_engine &e, HipEngineState *st) {
   e.diag_inverse = gpak_dev_diag_inverse; e.logdiag_block = gpak_dev_logdiag_block; e.kmatvec = gpak_dev_kmatvec;
   e.nlz_terms = gpak_dev_nlz_terms; e.pack = gpak_dev_pack; e.vec_scale = gpak_dev_vec_scale;
   e.vec_sum = gpak_dev_vec_sum;
+  e.grad_g_rows = gpak_dev_grad_g_rows; e.grad_binv_rows = gpak_dev_grad_binv_rows;
+  e.grad_pairs_rows = gpak_dev_grad_pairs_rows;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -228,6 +230,10 @@ struct gpak_dist {
   double *alpha = nullptr, *fwd_x = nullptr, *fwd_z = nullptr, *rhs = nullptr, *f = nullptr, *bwd_scratch = nullptr;
   double *ld_slots = nullptr;
   int *info = nullptr;
+  // gradient workspaces (allocated on the first gpak_dist_grad)
+  std::vector<double *> slabs;        // per rank: its rows of L^-T (rows_q x Np)
+  double *binv = nullptr, *gpart = nullptr, *gred = nullptr;
+  double grad_ms = 0;
   std::vector<double *> inv_own;      // per owned block: W/128 x 2 x 128 x 128
   std::vector<double *> panels;       // per block column: packed W x (Np - J), every rank keeps all of them
   std::vector<double *> invs;         // per block column: the inverses as received (owner: alias of inv_own)
@@ -293,6 +299,9 @@ static void release_problem(gpak_dist *h) {
     if (h->rinv[b]) E.release(E.self, h->rinv[b]);
   }
   for (double *p : h->inv_own) if (p) E.release(E.self, p);
+  for (double *p : h->slabs) if (p) E.release(E.self, p);
+  h->slabs.clear();
+  rel(h->binv); rel(h->gpart); rel(h->gred);
   h->panels.clear(); h->invs.clear(); h->rinv.clear(); h->rinv_ok.clear(); h->inv_own.clear();
   h->owned.clear();
   h->N = h->Np = 0;
@@ -818,6 +827,49 @@ int gpak_dist_get_alpha(gpak_dist *h, double *alpha_host) {
   set_device(h);
   DCHK(h->E.download(h->E.self, h->s_bulk, alpha_host, h->alpha, sizeof(double) * h->N));
   return GPAK_OK;
+}
+
+int gpak_dist_grad(gpak_dist *h, double *g) {
+  if (!h || !g) return GPAK_EINVAL;
+  double v;
+  int rc = gpak_dist_nlz(h, &v);   // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
+  if (rc) return rc;
+  set_device(h);
+  gpak_dist_engine &E = h->E;
+  gpak_dist_transport &T = h->T;
+  const int Np = h->Np, P = h->P, Tn = Np / GPAK_TILE;
+  auto tiles_of = [&](int q) { return Tn > q ? (Tn - q + P - 1) / P : 0; };
+  const int Tmax = tiles_of(0), Ta = tiles_of(h->rank);
+  if (h->slabs.empty()) {
+    h->slabs.assign(P, nullptr);
+    bool ok = true;
+    for (int q = 0; q < P && ok; q++) {
+      h->slabs[q] = (double *)E.alloc(E.self, sizeof(double) * std::max<size_t>(1, (size_t)tiles_of(q) * GPAK_TILE * Np));
+      ok = h->slabs[q] != nullptr;
+    }
+    h->binv = (double *)E.alloc(E.self, sizeof(double) * std::max<size_t>(1, (size_t)Ta * GPAK_TILE * P * Tmax * GPAK_TILE));
+    h->gpart = (double *)E.alloc(E.self, sizeof(double) * std::max<size_t>(1, (size_t)Ta * (Np / 64) * 16));
+    h->gred = (double *)E.alloc(E.self, sizeof(double) * 32);
+    if (!ok || !h->binv || !h->gpart || !h->gred) { h->err = "device allocation failed for the gradient workspaces"; return GPAK_ENOMEM; }
+  }
+  h->sync_used = 0; h->time_used = 0;
+  const size_t t0 = h->time_event(h->s_bulk);
+  DCHK(E.grad_g_rows(h->s_bulk, Np, h->nb, P, h->rank, h->panels.data(), h->invs.data(), h->slabs[h->rank]));
+  DCHK(hop_in(h));
+  for (int q = 0; q < P; q++)
+    if (tiles_of(q) > 0) DCHK(T.bcast(T.self, h->s_comm, h->slabs[q], (size_t)tiles_of(q) * GPAK_TILE * Np, q));
+  DCHK(hop_out(h));
+  DCHK(E.grad_binv_rows(h->s_bulk, Np, P, h->rank, h->slabs.data(), h->binv));
+  DCHK(E.grad_pairs_rows(h->s_bulk, h->u, h->cap, h->x_soa, Np, h->N, Np, h->y, h->f, h->alpha, h->binv, P, h->rank,
+                         h->expans, h->bias, h->sn2, h->mode, h->gpart, h->gred));
+  DCHK(hop_in(h));
+  DCHK(T.allreduce_sum(T.self, h->s_comm, h->gred, 16));
+  DCHK(hop_out(h));
+  const size_t t1 = h->time_event(h->s_bulk);
+  double red[17];
+  DCHK(E.download(E.self, h->s_bulk, red, h->gred, sizeof(red)));
+  E.event_elapsed_ms(E.self, h->ev_time[t0], h->ev_time[t1], &h->grad_ms);
+  return gpak_dev_grad_finish(h->expans, h->bias, h->sn2, h->N, red, g);
 }
 
 int gpak_dist_get_stats(gpak_dist *h, gpak_dist_stats *out) {

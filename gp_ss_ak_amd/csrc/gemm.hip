@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
 // ds_read issue slots next to the MFMAs.
 // ---------------------------------------------------------------------------------------
 // TRAILING only names the instantiation (the bulk trailing update gets its own line in rocprofv3 statistics).
-template <int RS_D, int RS_OCC, bool TRAILING>
+// K0MAP (the distributed gradient's B^-1 = G G^T on row-cyclic slabs of G): the k-loop of tile row ti starts at global
+// row block ti * cyc_tpb + cyc_lt0 (the cyc_* parameters are reused; no cyclic column map in that instantiation).
+template <int RS_D, int RS_OCC, bool TRAILING, bool K0MAP = false>
 __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double alpha, const double *A, long lda,
                                                                const double *B, long ldb, double beta, double *C,
                                                                long ldc, int rb0, int cb0, int lower_skip, int mt,
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
     const int ssel = (q >> 6) * 8 + (b & 7);
     const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
     int si, sj = 0;
-    if (lower_skip) {
+    if (lower_skip == 1) {   // 1: super-tiles of the lower triangle only; 2: all super-tiles, per-tile rule below
       int rem = ssel;
       while (sj < SC && rem >= SR - sj) { rem -= SR - sj; sj++; }
       si = sj + rem;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
     if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
   }
   int gct = tj, art = ti;
-  if (cyc_P) {
+  if (!K0MAP && cyc_P) {
     const int lt = cyc_lt0 + tj;
     gct = ((lt / cyc_tpb) * cyc_P + cyc_rank) * cyc_tpb + (lt % cyc_tpb);
     art = rb0 + ti;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
   const int wr = w & 1, wc = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   if (!TRAILING) __builtin_amdgcn_s_setprio(2);  // panel-chain products go ahead of the bulk update's waves
-  const int kstep0 = k0_by_row ? (rb0 + ti) * (TM / 4) : 0;
+  const int kstep0 = K0MAP ? (ti * cyc_tpb + cyc_lt0) * (TM / 4) : (k0_by_row ? (rb0 + ti) * (TM / 4) : 0);
   const int nk = K / 4;
   // One 16-B load feeds TWO fragments: lane (l15, l4) fetches rows 32h + 2*l15, +1 of k-column 4s + l4 and
   // uses them as its element of tiles 2h and 2h+1, i.e. MFMA tile i covers the rows 32(i>>1) + 2j + (i&1),
@@ -429,6 +431,20 @@ void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, -1.0, Pv, ldp, Pv, ldp, 1.0, Clocal, ldc,
                      rt0, 0, 0, mt, nt, 0, P, rank, tpb, lt0);
+}
+
+// C (mt x nt tiles) = alpha * A * B^T with the k-loop of tile row ti started at global row block ti*k0_mul + k0_add
+// (A and B are rows of an upper-triangular matrix held in row-cyclic slabs); tile (ti, tj) is skipped when
+// ti < tj + skip_shift.
+void gpak_launch_gemm_nt_k0map(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
+                               const double *B, long ldb, double *C, long ldc, int skip_shift, int k0_mul, int k0_add) {
+  if (mt <= 0 || nt <= 0) return;
+  const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
+  const long nsuper = (long)SR * SC;
+  dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
+  // lower_skip = 0 in the super-tile walk (every super-tile is visited); the per-tile rule is rb0 + ti < cb0 + tj
+  hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, 0.0, C, ldc, 0,
+                     skip_shift, 2, mt, nt, 0, 0, 0, k0_mul, k0_add);
 }
 
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,

@@ -249,6 +249,8 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
                          int col_block0, bool lower_skip, bool trailing, bool k0_by_row = false);
 
+void gpak_launch_gemm_nt_k0map(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
+                               const double *B, long ldb, double *C, long ldc, int skip_shift, int k0_mul, int k0_add);
 void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double *Pv, long ldp, double *Clocal,
                              long ldc, int rt0, int P, int rank, int tpb, int lt0);
 
@@ -303,3 +305,5 @@ void gpak_predict_release(gpak_ctx *ctx);
 
 // ---- grad.hip ---------------------------------------------------------------------------
 void gpak_grad_release(gpak_ctx *ctx);
+void gpak_grad_assemble(const KernParams &kp, const int *kinds, const double *expans, int d, int N, double sn2,
+                        const double *red, double *g);

@@ -13,10 +13,12 @@
 //   2. B^-1 = G G^T, lower tiles, k-loop started at the row tile (N^3/3 flops, MFMA);
 //   3. ONE fused pass over the pairs i >= j that recomputes K_ij from the coordinates and
 //      accumulates the nine sums the ten gradient entries are made of.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
 
+#include "../../include/gpak_dev.h"
 #include "gpak_internal.h"
 
 #define PB 128
@@ -51,8 +53,11 @@ __global__ void gpak_identity_f64(double *W, long ld, int n) {
 __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
     const double *__restrict__ U, int cap, const double *__restrict__ x0, const double *__restrict__ x1,
     const double *__restrict__ x2, const double *__restrict__ x3, const double *__restrict__ alpha,
-    const double *__restrict__ Binv, long ld, int N, KernParams kp, GradConsts gc, double *__restrict__ part) {
-  const int row0 = blockIdx.x * GT_ROWS, col0 = blockIdx.y * GT_COLS;
+    const double *__restrict__ Binv, long ld, int N, KernParams kp, GradConsts gc, double *__restrict__ part,
+    int rowP, int rowA, int Tmax) {
+  // rowP > 0 (distributed gradient): this rank holds the B^-1 ROWS of the 128-row blocks g = t*rowP + rowA as a
+  // compact (rows x Np) array whose 128-column groups are ordered by (g % rowP, g / rowP): see gpak_grad_binv_rows
+  const int row0 = (rowP ? blockIdx.x * rowP + rowA : blockIdx.x) * GT_ROWS, col0 = blockIdx.y * GT_COLS;
   const int bid = blockIdx.y * gridDim.x + blockIdx.x;
   __shared__ double cq[GPAK_MAX_TERMS][GPAK_PT][GT_COLS];  // transformed column points, per term
   __shared__ double cx3[GT_COLS];                    // raw 4th column of the column points (0 for 3-D)
@@ -86,6 +91,13 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
     }
     __syncthreads();
     const int r = row0 + 2 * lane;
+    // where row r / column j live in Binv
+    const long rloc = rowP ? (long)blockIdx.x * GT_ROWS + 2 * lane : (long)r;
+    long cgrp = 0;
+    if (rowP) {
+      const int g = col0 / PB;
+      cgrp = ((long)(g % rowP) * Tmax + g / rowP) * PB - (long)g * PB;   // added to j: the permuted column
+    }
     double pu[2][GPAK_MAX_TERMS][GPAK_PT], px[2][3], pa[2][6], pal[2], px3[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void gpak_grad_pairs_f64(
     for (int c = 0; c < GT_COLS / 4; c++) {
       const int jl = w + 4 * c, j = col0 + jl;
       if (j >= N) continue;
-      const double2 q2 = *reinterpret_cast<const double2 *>(Binv + r + (size_t)j * ld);
+      const double2 q2 = *reinterpret_cast<const double2 *>(Binv + rloc + (size_t)(j + cgrp) * ld);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int i = r + h;
@@ -272,6 +284,35 @@ static void build_grad_consts(const double *e, GradConsts &gc) {
   }
 }
 
+// the gradient entries from the NSUM pair sums + the lp_dhyp sum (red[NSUM]); children in order, bias, sn2
+void gpak_grad_assemble(const KernParams &kp, const int *kinds, const double *expans, int d, int N, double sn2,
+                        const double *red, double *g) {
+  int go = 0;
+  for (int t = 0; t < kp.nterms; t++) {
+    const KernTerm &T = kp.term[t];
+    const double A = red[9 + 2 * t], B = red[10 + 2 * t];
+    if (kinds[t] == GPAK_KERN_EXPANS) {
+      for (int p = 0; p < 6; p++) g[go + p] = red[p];            // Kernel.cpp:1195-1233
+      g[go + 6] = 2.0 * red[6] * expans[6];                      // :1241-1242
+      // :1246-1257: 0 for 3-D inputs; with a rock-type column -2 * sum(KD2 % Di2_R) / N, Di2_R = 2 dx4^2
+      g[go + 7] = d == 4 ? -4.0 * red[15] / (double)N : 0.0;
+      go += 8;
+    } else if (kinds[t] == GPAK_KERN_EXP) {                      // Kernel.cpp:671-690
+      g[go] = T.var2 * A;
+      g[go + 1] = B * sqrt(T.var2);
+      go += 2;
+    } else {                                                     // Kernel.cpp:512-538
+      g[go] = T.var2 * (T.iw / 2) * A;                           // g1/2 = -(sum R . D2), R = var2 QW KD2 (-iw/2)
+      g[go + 1] = -0.25 * T.var2 * A;                            // g2/2
+      g[go + 2] = T.var2 * B;                                    // g3/2 = sigma^2 sum QW . KD2
+      go += 3;
+    }
+  }
+  g[go++] = red[8];                                              // Kern_Bias::getGradients: trace(QW)
+  const double sum_dW = 0.5 * red[7];                            // dW = 0.5 * sum(Q % K, 1)
+  g[go] = -1.0 * sum_dW * (2.0 / sn2) - red[NSUM];               // GP_Utils.cpp:1226
+}
+
 // kinds of the current composition (set by gpak_set_params / gpak_set_kernel)
 int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng) {
   GPAK_HIP(hipSetDevice(ctx->device));
@@ -352,7 +393,7 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng) {
   if (rc) return rc;
   hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, ctx->U.base, ctx->U.cap, ctx->dX, ctx->dX + Np,
                      ctx->dX + 2 * (size_t)Np, ctx->d == 4 ? ctx->dX + 3 * (size_t)Np : (const double *)nullptr,
-                     ctx->dAlpha, ctx->dBinv, ld, N, ctx->kp, gc, ctx->dGpart);
+                     ctx->dAlpha, ctx->dBinv, ld, N, ctx->kp, gc, ctx->dGpart, 0, 0, 0);
   hipLaunchKernelGGL(gpak_grad_reduce_f64, dim3(NSUM), dim3(256), 0, st, ctx->dGpart, (int)nblocks, ctx->dRed + 8);
   hipLaunchKernelGGL(gpak_lpdhyp_f64, dim3(1), dim3(1024), 0, st, N, ctx->dy, ctx->dF, ctx->sn2, ctx->dRed + 8 + NSUM);
   double red[NSUM + 1];
@@ -362,29 +403,132 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng) {
   float ms = 0;
   GPAK_HIP(hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[3]));
   ctx->times.grad_ms = ms;
-  int go = 0;
-  for (int t = 0; t < ctx->kp.nterms; t++) {
-    const KernTerm &T = ctx->kp.term[t];
-    const double A = red[9 + 2 * t], B = red[10 + 2 * t];
-    if (ctx->kinds[t] == GPAK_KERN_EXPANS) {
-      for (int p = 0; p < 6; p++) g[go + p] = red[p];            // Kernel.cpp:1195-1233
-      g[go + 6] = 2.0 * red[6] * ctx->expans[6];                 // :1241-1242
-      // :1246-1257: 0 for 3-D inputs; with a rock-type column -2 * sum(KD2 % Di2_R) / N, Di2_R = 2 dx4^2
-      g[go + 7] = ctx->d == 4 ? -4.0 * red[15] / (double)N : 0.0;
-      go += 8;
-    } else if (ctx->kinds[t] == GPAK_KERN_EXP) {                 // Kernel.cpp:671-690
-      g[go] = T.var2 * A;
-      g[go + 1] = B * sqrt(T.var2);
-      go += 2;
-    } else {                                                     // Kernel.cpp:512-538
-      g[go] = T.var2 * (T.iw / 2) * A;                           // g1/2 = -(sum R . D2), R = var2 QW KD2 (-iw/2)
-      g[go + 1] = -0.25 * T.var2 * A;                            // g2/2
-      g[go + 2] = T.var2 * B;                                    // g3/2 = sigma^2 sum QW . KD2
-      go += 3;
+  gpak_grad_assemble(ctx->kp, ctx->kinds, ctx->expans, ctx->d, N, ctx->sn2, red, g);
+  return GPAK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The same gradient distributed over P ranks that all hold the factor as packed panels (csrc/dist.hip).
+// G = L^-T is upper triangular and its ROWS are independent right-hand sides of the blocked forward substitution
+// (the test-major scheme of predict.hip): rank a computes the rows of the 128-row blocks g = t*P + a into a compact
+// slab (rows_a x Np, leading dimension rows_a) -- N^3/(3P) flops, no communication; the slabs are all-gathered (the
+// caller's broadcasts); B^-1 rows of the same blocks = sum_k G[I,k] G[J,k] for J <= I against every rank's slab --
+// N^3/(3P) flops; then the pair pass on those rows and one all-reduce of the NSUM sums.
+// ---------------------------------------------------------------------------------------
+__global__ void gpak_slab_identity_f64(double *W, int rows, int Np, int P, int a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)rows * Np;
+  if (i >= tot) return;
+  const int c = (int)(i / rows), r = (int)(i - (size_t)c * rows);
+  const int grow = ((r / PB) * P + a) * PB + (r % PB);   // global row of local row r
+  W[i] = (grow == c) ? 1.0 : 0.0;
+}
+
+void gpak_build_siginv(const double *e, double *A);   // api.hip
+
+static int my_tiles(int Np, int P, int a) { const int T = Np / PB; return T > a ? (T - a + P - 1) / P : 0; }
+
+extern "C" int gpak_dev_grad_g_rows(void *stream, int Np, int nb, int P, int a, const double *const *panels,
+                                    const double *const *invs, double *slab) {
+  hipStream_t st = (hipStream_t)stream;
+  const int Ta = my_tiles(Np, P, a);
+  if (Ta == 0) return GPAK_OK;
+  const long rows = (long)Ta * PB;
+  const size_t tot = (size_t)rows * Np;
+  hipLaunchKernelGGL(gpak_slab_identity_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slab, (int)rows, Np, P, a);
+  auto tiles_upto = [&](int gblock) { return gblock >= a ? std::min(Ta, (gblock - a) / P + 1) : 0; };   // g <= gblock
+  for (int b = 0, J = 0; J < Np; b++, J += nb) {
+    const int W = std::min(nb, Np - J);
+    const long ldp = Np - J;
+    const double *panel = panels[b];
+    for (int j0 = J; j0 < J + W; j0 += PB) {
+      const int mt = tiles_upto(j0 / PB);   // rows below are still zero in L^-T
+      if (mt == 0) continue;
+      const double *inv = invs[b] + (size_t)((j0 - J) / PB) * 2 * PB * PB;
+      double *Wj = slab + (size_t)j0 * rows;
+      gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Wj, rows, inv, PB, 0.0, Wj, rows, 0, 0, false, false);
+      const int nin = (J + W - j0 - PB) / PB;
+      if (nin > 0)
+        gpak_launch_gemm_nt(st, mt, nin, PB, -1.0, Wj, rows, panel + (j0 + PB - J) + (size_t)(j0 - J) * ldp, ldp, 1.0,
+                            slab + (size_t)(j0 + PB) * rows, rows, 0, 0, false, false);
     }
+    const int nrest = (Np - J - W) / PB, mt2 = tiles_upto((J + W) / PB - 1);
+    if (nrest > 0 && mt2 > 0)
+      gpak_launch_gemm_nt(st, mt2, nrest, W, -1.0, slab + (size_t)J * rows, rows, panel + W, ldp, 1.0,
+                          slab + (size_t)(J + W) * rows, rows, 0, 0, false, false);
   }
-  g[go++] = red[8];                                              // Kern_Bias::getGradients: trace(QW)
-  const double sum_dW = 0.5 * red[7];                            // dW = 0.5 * sum(Q % K, 1)
-  g[go] = -1.0 * sum_dW * (2.0 / ctx->sn2) - red[NSUM];          // GP_Utils.cpp:1226
+  return hipGetLastError() == hipSuccess ? GPAK_OK : GPAK_EHIP;
+}
+
+// binv: rows_a x (P * Tmax * 128), leading dimension rows_a; the 128-column group of global block g = u*P + b sits at
+// group index b*Tmax + u (so that one launch per source slab writes a contiguous range of tile columns)
+extern "C" int gpak_dev_grad_binv_rows(void *stream, int Np, int P, int a, const double *const *slabs, double *binv) {
+  hipStream_t st = (hipStream_t)stream;
+  const int Ta = my_tiles(Np, P, a), Tmax = my_tiles(Np, P, 0);
+  if (Ta == 0) return GPAK_OK;
+  const long rows = (long)Ta * PB;
+  for (int b = 0; b < P; b++) {
+    const int Tb = my_tiles(Np, P, b);
+    if (Tb == 0) continue;
+    // tile (t, u): global row block t*P + a, global column block u*P + b; needed when u*P + b <= t*P + a, i.e.
+    // skipped when t < u + (b > a ? 1 : 0)
+    gpak_launch_gemm_nt_k0map(st, Ta, Tb, Np, 1.0, slabs[a], rows, slabs[b], (long)Tb * PB,
+                              binv + (size_t)b * Tmax * PB * rows, rows, b > a ? 1 : 0, P, a);
+  }
+  return hipGetLastError() == hipSuccess ? GPAK_OK : GPAK_EHIP;
+}
+
+// out[0..NSUM) = this rank's share of the pair sums, out[NSUM] = sum_i ((y_i - f_i)^2 / sn2 - 1) (replicated: NOT to
+// be all-reduced); part: Ta * (Np / 64) * NSUM doubles of scratch
+extern "C" int gpak_dev_grad_pairs_rows(void *stream, const double *u, int cap, const double *x_soa, int xs, int n, int Np,
+                                        const double *y, const double *f, const double *alpha, const double *binv, int P,
+                                        int a, const double *expans, double bias, double sn2, int dist_mode, double *part,
+                                        double *out) {
+  hipStream_t st = (hipStream_t)stream;
+  const int Ta = my_tiles(Np, P, a), Tmax = my_tiles(Np, P, 0);
+  KernParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.nterms = 1;
+  gpak_build_siginv(expans, kp.term[0].A);
+  kp.term[0].var2 = expans[6] * expans[6];
+  kp.term[0].profile = GPAK_PROFILE_EXPSQRT;
+  kp.d = 3; kp.bias = bias; kp.mode = dist_mode;
+  GradConsts gc;
+  memset(&gc, 0, sizeof(gc));
+  build_grad_consts(expans, gc);
+  gc.var2 = kp.term[0].var2; gc.bias = bias; gc.sn2 = sn2; gc.mode = dist_mode; gc.te = 0;
+  gc.kinds[0] = GPAK_KERN_EXPANS; gc.kinds[1] = gc.kinds[2] = -1;
+  hipMemsetAsync(out, 0, sizeof(double) * (NSUM + 1), st);
+  if (Ta > 0) {
+    dim3 grid(Ta, Np / GT_COLS);
+    const int nblocks = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, u, cap, x_soa, x_soa + xs, x_soa + 2 * (size_t)xs,
+                       (const double *)nullptr, alpha, binv, (long)Ta * PB, n, kp, gc, part, P, a, Tmax);
+    hipLaunchKernelGGL(gpak_grad_reduce_f64, dim3(NSUM), dim3(256), 0, st, part, nblocks, out);
+  }
+  hipLaunchKernelGGL(gpak_lpdhyp_f64, dim3(1), dim3(1024), 0, st, n, y, f, sn2, out + NSUM);
+  return hipGetLastError() == hipSuccess ? GPAK_OK : GPAK_EHIP;
+}
+
+// the constants of the pair pass (M_p = S % S_p as {00,01,02,11,12,22}, and 2 * its column sums): exported so that a
+// test engine can restate the pass without restating Kernel.cpp:955-1166 a third time
+extern "C" int gpak_dev_grad_consts(const double *expans, double *M36, double *m2_18) {
+  GradConsts gc;
+  memset(&gc, 0, sizeof(gc));
+  build_grad_consts(expans, gc);
+  memcpy(M36, gc.M, sizeof(double) * 36);
+  memcpy(m2_18, gc.m2, sizeof(double) * 18);
+  return GPAK_OK;
+}
+
+// host side of the distributed gradient: g[10] from the all-reduced sums
+extern "C" int gpak_dev_grad_finish(const double *expans, double bias, double sn2, int n, const double *red, double *g) {
+  KernParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.nterms = 1;
+  kp.term[0].var2 = expans[6] * expans[6];
+  kp.bias = bias;
+  const int kinds[GPAK_MAX_TERMS] = {GPAK_KERN_EXPANS, 0, 0};
+  gpak_grad_assemble(kp, kinds, expans, 3, n, sn2, red, g);
   return GPAK_OK;
 }

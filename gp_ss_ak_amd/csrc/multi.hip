@@ -3,7 +3,8 @@
 //   * one rank of the C++ block-column-cyclic schedule (csrc/dist.hip) -- logLikelihood / alpha on all GPUs;
 //   * lazily, a full single-GPU context on its device (a replica of the model) -- the prediction is sharded over
 //     the test points with the factor replicated ("embarrassingly parallel if L is replicated"),
-//     and the calls that are not distributed (gradient, Gram copies, solve_chol) run on the replica of device 0.
+//     and the calls that are not distributed (Gram copies, solve_chol, gradients of other compositions) run on the
+//     replica of device 0.  The ExpAns(+Bias) gradient is distributed (gpak_dist_grad).
 // Collectives between the threads: RCCL (one communicator per thread, ncclCommInitRank with a shared id), or --
 // when RCCL cannot be used (several ranks on ONE device, which is all a test box has; GPAK_MULTI_TRANSPORT=local;
 // a failed RCCL start-up) -- an in-process transport: the root publishes its buffer and an event, the receivers
@@ -342,6 +343,15 @@ int gpak_multi_alpha(gpak_multi *g, double *alpha_host) {
   rc = g->run([&](int r) { return r == 0 ? gpak_dist_get_alpha(g->ranks[0], alpha_host) : (int)GPAK_OK; });
   if (rc) g->err = gpak_dist_last_error(g->ranks[0]);
   return rc;
+}
+
+// GP_utils::GradLL on the group: B^-1 by row blocks over the ranks (gpak_dist_grad)
+int gpak_multi_grad(gpak_multi *g, double *grad10) {
+  std::vector<std::vector<double>> gs(g->P, std::vector<double>(10, 0.0));
+  int rc = g->run([&](int r) { return gpak_dist_grad(g->ranks[r], gs[r].data()); });
+  if (rc) { g->err = gpak_dist_last_error(g->ranks[0]); return rc; }
+  memcpy(grad10, gs[0].data(), sizeof(double) * 10);
+  return GPAK_OK;
 }
 
 int gpak_multi_stats(gpak_multi *g, int r, gpak_dist_stats *out) { return gpak_dist_get_stats(g->ranks[r], out); }

@@ -54,6 +54,10 @@ ENGINE_FIELDS = [
     ("pack", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp)),
     ("vec_scale", _F(C.c_int, _vp, C.c_int, _vp, C.c_double, _vp)),
     ("vec_sum", _F(C.c_int, _vp, C.c_int, _vp, _vp)),
+    ("grad_g_rows", _F(C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp), _vp)),
+    ("grad_binv_rows", _F(C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), _vp)),
+    ("grad_pairs_rows", _F(C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                           _dp, C.c_double, C.c_double, C.c_int, _vp, _vp)),
 ]
 
 
@@ -80,7 +84,7 @@ class Stats(C.Structure):
 
 DIST_SYMBOLS = ["gpak_dist_create", "gpak_dist_destroy", "gpak_dist_last_error", "gpak_dist_rccl_unique_id",
                 "gpak_dist_init_rccl", "gpak_dist_selfcheck", "gpak_dist_set_train", "gpak_dist_set_params",
-                "gpak_dist_nlz", "gpak_dist_nlz_terms", "gpak_dist_get_alpha", "gpak_dist_get_stats",
+                "gpak_dist_nlz", "gpak_dist_nlz_terms", "gpak_dist_grad", "gpak_dist_get_alpha", "gpak_dist_get_stats",
                 "gpak_dev_vec_scale", "gpak_dev_vec_sum"]
 
 
@@ -102,6 +106,7 @@ def _load():
     lib.gpak_dist_nlz.argtypes = [_vp, _dp]
     lib.gpak_dist_nlz_terms.argtypes = [_vp, _dp, _dp, _dp]
     lib.gpak_dist_get_alpha.argtypes = [_vp, _dp]
+    lib.gpak_dist_grad.argtypes = [_vp, _dp]
     lib.gpak_dist_get_stats.argtypes = [_vp, C.POINTER(Stats)]
     return lib
 
@@ -212,6 +217,12 @@ class DistRank:
         q, s, l = C.c_double(), C.c_double(), C.c_double()
         self._check(self._lib.gpak_dist_nlz_terms(self._h, C.byref(q), C.byref(s), C.byref(l)))
         return q.value, s.value, l.value
+
+    def grad(self):
+        """GradLL as written, g[10] = {8 ExpAns, bias, sn2}; distributed by row blocks of B^-1."""
+        g = np.zeros(10)
+        self._check(self._lib.gpak_dist_grad(self._h, g.ctypes.data_as(_dp)))
+        return g
 
     def get_alpha(self):
         a = np.zeros(self.N)

@@ -61,8 +61,9 @@ int  gpak_create(gpak_ctx **out, int device, int precision);
 /* ONE process driving n_gpus devices (devices[r] = HIP ordinal of rank r; NULL = 0 .. n_gpus-1): the same gpak_ctx
  * surface -- `gp_ss_ak --gpus n` runs on it.  logLikelihood / alpha run on the block-column-cyclic schedule of
  * gpak_dist.h over all devices (RCCL panel broadcasts; an in-process peer-copy transport when RCCL cannot start or
- * several ranks share a device); prediction is sharded over the test points with the factor replicated per device;
- * gradient, Gram copies and solve_chol run on a replica of the model on devices[0].  3-D inputs, ExpAns(+Bias). */
+ * several ranks share a device); the gradient is distributed by row blocks of B^-1 (gpak_dist_grad); prediction is
+ * sharded over the test points with the factor replicated per device; Gram copies and solve_chol run on a replica of
+ * the model on devices[0].  3-D inputs, ExpAns(+Bias). */
 int  gpak_create_multi(gpak_ctx **out, int n_gpus, const int *devices, int precision);
 int  gpak_n_gpus(const gpak_ctx *ctx);
 void gpak_destroy(gpak_ctx *ctx);

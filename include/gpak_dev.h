@@ -85,6 +85,26 @@ int gpak_dev_nlz_terms(void *stream, int N, const double *y, const double *f, co
  * dimension ld): the panel pack in front of a broadcast. */
 int gpak_dev_pack(void *stream, const double *src, long ld, int row0, int nrows, int ncols, double *dst);
 
+/* ---- the reference-style gradient (GP_utils::GradLL, GP_Utils.cpp:1171-1262) distributed over P ranks that all hold
+ * the factor as packed panels.  128-row block g of G = L^-T and of B^-1 belongs to rank g % P.
+ * panels / invs / slabs are HOST arrays of device pointers (one per block column / per rank).
+ * gpak_dev_grad_g_rows: slab (rows_a x Np doubles, leading dimension rows_a = 128 * number of owned row blocks) <- the
+ *   owned rows of L^-T by blocked forward substitution on identity rows (N^3/(3P) flops).
+ * gpak_dev_grad_binv_rows: binv (rows_a x P*Tmax*128, Tmax = ceil(Np/128 / P)) <- the owned rows of B^-1 = G G^T,
+ *   lower part; the 128-column group of global block g sits at group index (g % P) * Tmax + g / P.
+ * gpak_dev_grad_pairs_rows: out[0..16) <- this rank's share of the pair sums (to be all-reduced), out[16] <- the
+ *   replicated lp_dhyp sum; part = scratch of rows_a/128 * Np/64 * 16 doubles.
+ * gpak_dev_grad_finish (host only): g[10] = {8 ExpAns, bias, sn2} from the all-reduced sums. */
+int gpak_dev_grad_g_rows(void *stream, int Np, int nb, int P, int a, const double *const *panels,
+                         const double *const *invs, double *slab);
+int gpak_dev_grad_binv_rows(void *stream, int Np, int P, int a, const double *const *slabs, double *binv);
+int gpak_dev_grad_pairs_rows(void *stream, const double *u, int cap, const double *x_soa, int xs, int n, int Np,
+                             const double *y, const double *f, const double *alpha, const double *binv, int P, int a,
+                             const double *expans, double bias, double sn2, int dist_mode, double *part, double *out);
+int gpak_dev_grad_finish(const double *expans, double bias, double sn2, int n, const double *red, double *g);
+/* host only: the constants of the pair pass, M36 = M_p (6 x {00,01,02,11,12,22}), m2_18 = 2 * column sums of M_p */
+int gpak_dev_grad_consts(const double *expans, double *M36, double *m2_18);
+
 /* A HIP stream that may not use the first skip_cus compute units (hipExtStreamCreateWithCUMask): the bulk
  * updates of a rank run there, so that the serial panel chain (potrf128, the small panel products) always finds
  * idle CUs beside them.  skip_cus = 0 gives an ordinary non-blocking stream.  Wrap it for torch with

@@ -78,6 +78,13 @@ typedef struct gpak_dist_engine {
   int (*pack)(void *stream, const double *src, long ld, int row0, int nrows, int ncols, double *dst);
   int (*vec_scale)(void *stream, int n, const double *in, double s, double *out);
   int (*vec_sum)(void *stream, int n, const double *in, double *out);   /* out[0] = in[0] + ... + in[n-1], fixed order */
+  /* the distributed gradient (gpak_dev.h) */
+  int (*grad_g_rows)(void *stream, int Np, int nb, int P, int a, const double *const *panels, const double *const *invs,
+                     double *slab);
+  int (*grad_binv_rows)(void *stream, int Np, int P, int a, const double *const *slabs, double *binv);
+  int (*grad_pairs_rows)(void *stream, const double *u, int cap, const double *x_soa, int xs, int n, int Np,
+                         const double *y, const double *f, const double *alpha, const double *binv, int P, int a,
+                         const double *expans, double bias, double sn2, int dist_mode, double *part, double *out);
 } gpak_dist_engine;
 
 /* Collectives on device buffers, enqueued on `stream` (an engine stream) in call order; every rank calls them in
@@ -120,6 +127,12 @@ int gpak_dist_set_params(gpak_dist *h, const double *expans, double bias, double
  * Same value on every rank; quiet NaN with GPAK_ENOTPD on Chol_fail. */
 int gpak_dist_nlz(gpak_dist *h, double *nlz);
 int gpak_dist_nlz_terms(gpak_dist *h, double *quad, double *sumlp, double *logdet);
+/* GP_utils::GradLL (GP_Utils.cpp:1171-1262) with the children's getGradients as written (Kernel.cpp:886-1263, 370-377),
+ * g[10] = {8 ExpAns, bias, sn2}, same value on every rank.  Distributed by 128-row blocks of L^-T and B^-1 (block g on
+ * rank g % P): each rank forms its rows of L^-T from the packed panels it already holds (N^3/(3P) flops, no
+ * communication), the row slabs are all-gathered (P broadcasts, N^2 doubles in total), each rank forms its rows of
+ * B^-1 = L^-T L^-1 (N^3/(3P)) and runs the fused pair pass on them; one 16-double all-reduce. */
+int gpak_dist_grad(gpak_dist *h, double *g);
 /* alpha = (K + sn2 I)^-1 y of the last gpak_dist_nlz (replicated), N doubles */
 int gpak_dist_get_alpha(gpak_dist *h, double *alpha_host);
 

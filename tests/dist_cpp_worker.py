@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--mode", type=int, default=1)
     ap.add_argument("--sn2", type=float, default=None)
     ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--grad", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -52,6 +53,8 @@ def main():
     if nlz == nlz:
         q, s, l = gp.nlz_terms()
         res.update({"alpha": gp.get_alpha().tolist(), "logdet": l, "quad": q, "sumlp": s})
+        if a.grad:
+            res["grad"] = gp.grad().tolist()
     if eng is not None:
         # schedule facts the tests assert: which stream every factor / update was issued on
         res["calls"] = [(op, int(arg), int(st_)) for op, arg, st_ in eng.calls]

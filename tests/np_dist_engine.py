@@ -128,6 +128,90 @@ class NumpyDistEngine:
         def pack(st, src, ld, row0, nrows, ncols, dst):
             _strided(dst, nrows, ncols, nrows)[:] = _strided(int(src) + 8 * row0, nrows, ncols, ld)
 
+        # ---- distributed gradient (gpak_dev_grad_*): dense restatements on the reconstructed factor ----------
+        def my_tiles(Np, P, a):
+            T = Np // TILE
+            return (T - a + P - 1) // P if T > a else 0
+
+        def my_rows(Np, P, a):
+            return np.concatenate([np.arange((t * P + a) * TILE, (t * P + a + 1) * TILE) for t in range(my_tiles(Np, P, a))]
+                                  or [np.zeros(0, dtype=int)]).astype(int)
+
+        def grad_g_rows(st, Np, nb, P, a, panels, invs, slab):
+            L = np.zeros((Np, Np))
+            for b, J in enumerate(range(0, Np, nb)):
+                W = min(nb, Np - J)
+                L[J:, J:J + W] = _strided(panels[b], Np - J, W, Np - J)
+            G = np.linalg.inv(np.tril(L)).T
+            rows = my_rows(Np, P, a)
+            if len(rows):
+                _strided(slab, len(rows), Np, len(rows))[:] = G[rows, :]
+
+        def grad_binv_rows(st, Np, P, a, slabs, binv):
+            G = np.zeros((Np, Np))
+            for q in range(P):
+                rq = my_rows(Np, P, q)
+                if len(rq):
+                    G[rq, :] = _strided(slabs[q], len(rq), Np, len(rq))
+            rows, Tmax = my_rows(Np, P, a), my_tiles(Np, P, 0)
+            if not len(rows):
+                return
+            Bi = G[rows, :] @ G.T                                    # my rows of B^-1 = G G^T
+            out = _strided(binv, len(rows), P * Tmax * TILE, len(rows))
+            out[:] = 0.0
+            for g in range(Np // TILE):
+                c0 = ((g % P) * Tmax + g // P) * TILE
+                out[:, c0:c0 + TILE] = Bi[:, g * TILE:(g + 1) * TILE]
+
+        def grad_pairs_rows(st, u, cap, x_soa, xs, n, Np, y, f, alpha, binv, P, a, expans, bias, sn2, mode, part, out):
+            lib = gd._load()
+            e = np.array([expans[i] for i in range(8)])
+            M36, m2 = np.zeros(36), np.zeros(18)
+            lib.gpak_dev_grad_consts.argtypes = [gd._dp, gd._dp, gd._dp]
+            lib.gpak_dev_grad_consts(e.ctypes.data_as(gd._dp), M36.ctypes.data_as(gd._dp), m2.ctypes.data_as(gd._dp))
+            Mp = np.zeros((6, 3, 3))
+            for p in range(6):
+                v = M36[6 * p:6 * p + 6]
+                Mp[p] = [[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]]
+            m2 = m2.reshape(6, 3)
+            un = _arr(u, 5 * cap).reshape(5, cap)
+            X = _arr(x_soa, 3 * xs).reshape(3, xs)[:, :n].T
+            al, yn, fn = _arr(alpha, Np)[:n], _arr(y, Np)[:n], _arr(f, Np)[:n]
+            rows, Tmax = my_rows(Np, P, a), my_tiles(Np, P, 0)
+            acc = np.zeros(17)
+            acc[16] = float(((yn - fn) ** 2 / sn2 - 1.0).sum())
+            rows = rows[rows < n]
+            if len(rows):
+                Bperm = _strided(binv, my_tiles(Np, P, a) * TILE, P * Tmax * TILE, my_tiles(Np, P, a) * TILE)
+                cols = np.arange(n)
+                cperm = ((cols // TILE % P) * Tmax + cols // TILE // P) * TILE + cols % TILE
+                loc = np.concatenate([np.arange(t * TILE, (t + 1) * TILE) for t in range(my_tiles(Np, P, a))])[:len(rows)]
+                Q = Bperm[loc][:, cperm]                              # (my rows) x n
+                Pu, Qu = un[:3, rows].T, un[:3, :n].T
+                if mode == 1:
+                    D2 = ((Pu[:, None, :] - Qu[None, :, :]) ** 2).sum(-1)
+                else:
+                    D2 = np.maximum(un[3, rows][:, None] + un[3, :n][None, :] - 2 * Pu @ Qu.T, 0.0)
+                low = rows[:, None] >= cols[None, :]
+                diag = rows[:, None] == cols[None, :]
+                wgt = np.where(diag, 1.0, 2.0) * low
+                sd = np.sqrt(D2)
+                ek = np.exp(-sd)
+                var2 = e[6] ** 2
+                QW = Q / sn2 - al[rows][:, None] * al[None, :]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    dk = np.where((sd == 0) | diag, 0.0, ek * (-0.5 / sd))
+                rm = var2 * QW * dk
+                acc[7] = (wgt * Q * (bias + var2 * ek)).sum()
+                acc[8] = (QW * diag).sum()
+                acc[6] = (wgt * QW * ek).sum()
+                for p in range(6):
+                    pa_i = (X[rows] ** 2) @ m2[p]
+                    pa_j = (X ** 2) @ m2[p]
+                    di2 = pa_i[:, None] + pa_j[None, :] - 4.0 * (X[rows] @ Mp[p] @ X.T)
+                    acc[p] = (wgt * rm * di2).sum()
+            _arr(out, 17)[:] = acc
+
         def vec_scale(st, n, a, s, out):
             _arr(out, n)[:] = _arr(a, n) * s
 
@@ -143,7 +227,8 @@ class NumpyDistEngine:
             "update_block": ok(update_block), "update_cyclic": ok(update_cyclic), "trsv_fwd_block": ok(trsv_fwd_block),
             "trsv_bwd_packed": ok(trsv_bwd_packed), "diag_inverse": ok(diag_inverse), "logdiag_block": ok(logdiag_block),
             "kmatvec": ok(kmatvec), "nlz_terms": ok(nlz_terms), "pack": ok(pack), "vec_scale": ok(vec_scale),
-            "vec_sum": ok(vec_sum),
+            "vec_sum": ok(vec_sum), "grad_g_rows": ok(grad_g_rows), "grad_binv_rows": ok(grad_binv_rows),
+            "grad_pairs_rows": ok(grad_pairs_rows),
         }
         self._keep = {name: F[name](fn) for name, fn in impl.items()}
         self.table = gd.Engine(None, *[self._keep[name] for name, _ in gd.ENGINE_FIELDS[1:]])

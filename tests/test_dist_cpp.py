@@ -32,14 +32,14 @@ def free_port():
     return p
 
 
-def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900):
+def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0):
     port = free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
         for r in range(world):
             cmd = [sys.executable, os.path.join(HERE, "dist_cpp_worker.py"), "--rank", str(r), "--world", str(world),
                    "--port", str(port), "--n", str(n), "--nb", str(nb), "--engine", engine, "--mode", str(mode),
-                   "--steps", str(steps), "--out", os.path.join(d, f"r{r}.json")]
+                   "--steps", str(steps), "--grad", str(grad), "--out", os.path.join(d, f"r{r}.json")]
             if sn2 is not None:
                 cmd += ["--sn2", str(sn2)]
             env = dict(os.environ, OMP_NUM_THREADS="2")
@@ -81,6 +81,22 @@ def test_cpp_schedule_over_gloo_matches_oracle(orc, world, n, nb):
     assert len({r["stats"]["bytes_broadcast"] for r in res}) == 1 and res[0]["stats"]["bytes_broadcast"] > 0
 
 
+@pytest.mark.parametrize("world,n,nb,mode", [(1, 300, 128, 1), (2, 700, 256, 1), (3, 1000, 256, 1), (4, 1400, 512, 0)])
+def test_cpp_distributed_gradient_over_gloo_matches_oracle(orc, world, n, nb, mode):
+    """gpak_dist_grad: rows of L^-T from the packed panels, all-gather, rows of B^-1, pair pass, 16-double all-reduce
+    -- against GradLL + getGradients as written in the oracle (orc_grad_ref)."""
+    res = run_world(world, n, nb, grad=1, mode=mode)
+    X, y = synth.drillholes(n)
+    e = np.array(synth.DEFAULT_EXPANS)
+    K = orc.gram(X, X, e, synth.DEFAULT_BIAS, mode)
+    info, alpha, L = orc.nlz_lean(K, y, synth.DEFAULT_SN2)
+    go = orc.grad_ref(X, y, K, L, alpha, e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, mode)
+    tol = 1e-8 if mode == 1 else 1e-5
+    for r in res:
+        assert np.abs(np.array(r["grad"]) - go).max() <= tol * np.abs(go).max(), (r["rank"], r["grad"], go.tolist())
+    assert all(r["grad"] == res[0]["grad"] for r in res)            # bit-identical on every rank
+
+
 def test_cpp_schedule_repeated_steps_and_expansion_mode(orc):
     res = run_world(3, 900, 256, steps=3, mode=0)
     info, alpha = oracle_ref(orc, 900, mode=0)
@@ -103,6 +119,19 @@ def test_cpp_schedule_hip_engine_matches_oracle(orc, world, n, nb):
         assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
         assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
         assert r["stats"]["bulk_flops"] >= 0 and r["stats"]["factor_ms"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,nb", [(1, 1000, 256), (2, 1500, 256), (3, 2500, 512), (4, 5000, 512)])
+def test_cpp_distributed_gradient_hip_engine_matches_oracle(orc, world, n, nb):
+    res = run_world(world, n, nb, engine="hip", grad=1)
+    X, y = synth.drillholes(n)
+    e = np.array(synth.DEFAULT_EXPANS)
+    K = orc.gram(X, X, e, synth.DEFAULT_BIAS, 1)
+    info, alpha, L = orc.nlz_lean(K, y, synth.DEFAULT_SN2)
+    go = orc.grad_ref(X, y, K, L, alpha, e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, 1)
+    for r in res:
+        assert np.abs(np.array(r["grad"]) - go).max() <= 1e-8 * np.abs(go).max(), (r["rank"], r["grad"], go.tolist())
 
 
 @pytest.mark.gpu
