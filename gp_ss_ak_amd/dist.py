@@ -167,7 +167,11 @@ class DistRank:
             raise DistError(rc, "gpak_dist_create failed (no gfx950 device? there is no CPU fallback)")
         self._h = h
         self.rank, self.world = rank, world
-        if transport is None and world > 1:
+        # GPAK_DIST_RCCL_WORLD1=1 (tests): a ONE-rank RCCL communicator, so that a one-GPU box exercises the library's
+        # RCCL binding (dlopen, ncclCommInitRank, ncclBroadcast / ncclAllReduce on the communication stream) at all
+        if transport is None and world == 1 and os.environ.get("GPAK_DIST_RCCL_WORLD1") and rccl_id is None:
+            rccl_id = self.rccl_unique_id()
+        if transport is None and (world > 1 or rccl_id is not None):
             if rccl_id is None:
                 raise ValueError("the RCCL transport needs the unique id made on rank 0 (rccl_unique_id())")
             self._check(self._lib.gpak_dist_init_rccl(self._h, rccl_id))

@@ -160,6 +160,32 @@ def _single(size):
 
 
 @pytest.mark.gpu
+def test_rccl_binding_with_a_one_rank_communicator(orc):
+    """The built-in RCCL transport on the one GPU a test box has: a ONE-rank communicator (ncclGetUniqueId,
+    ncclCommInitRank through dlopen) carries every broadcast and all-reduce of two steps and a gradient."""
+    from gp_ss_ak_amd import dist as gd
+    os.environ["GPAK_DIST_RCCL_WORLD1"] = "1"
+    try:
+        gp = gd.DistRank(0, 1, device=0)
+    finally:
+        del os.environ["GPAK_DIST_RCCL_WORLD1"]
+    n = 1500
+    X, y = synth.drillholes(n)
+    gp.set_train(X, y, nb=256)
+    info, alpha = oracle_ref(orc, n)
+    for _ in range(2):
+        gp.set_params(synth.DEFAULT_EXPANS, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, 1)
+        assert abs(gp.nlz() - info.nlz) <= 1e-9 * abs(info.nlz)
+    assert np.abs(gp.get_alpha() - alpha).max() <= 1e-8 * np.abs(alpha).max()
+    K = orc.gram(X, X, synth.DEFAULT_EXPANS, synth.DEFAULT_BIAS, 1)
+    i2, a2, L2 = orc.nlz_lean(K, y, synth.DEFAULT_SN2)
+    go = orc.grad_ref(X, y, K, L2, a2, np.array(synth.DEFAULT_EXPANS), synth.DEFAULT_BIAS, synth.DEFAULT_SN2, 1)
+    assert np.abs(gp.grad() - go).max() <= 1e-8 * np.abs(go).max()
+    assert gp.stats()["bytes_broadcast"] > 0
+    gp.close()
+
+
+@pytest.mark.gpu
 def test_bench_distributed_entry_point_over_rccl_one_rank():
     """bench.py --gpus path exactly as the driver launches it (torch.distributed.run), the C++ schedule with the
     built-in RCCL transport and the one rank this box has; the step must agree with the single-context path."""
