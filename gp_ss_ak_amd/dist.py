@@ -293,6 +293,8 @@ def bench(args):
                          f"got WORLD_SIZE={world}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # one node: the control plane talks over loopback (a container's hostname need not resolve)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     # host-side control plane only (unique id, barriers, max over ranks): gloo.  The data path -- every panel
     # broadcast and all-reduce -- is RCCL inside libgpak_hip.so.
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))

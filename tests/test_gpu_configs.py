@@ -187,3 +187,39 @@ def test_config5_fp32_prediction_at_32768(gp):
     finally:
         g32.close()
         gp.set_train(X[:64], y[:64])
+
+
+def test_config4_n65536_sharded_over_four_ranks(gp):
+    """configs[3]: N=65536 fp64, block-column-cyclic Cholesky with sub-panel broadcasts -- rehearsed with FOUR ranks of
+    the C++ schedule on this box's one GPU (gpak_create_multi, in-process peer-copy transport; RCCL refuses several
+    ranks per device), against the single-context path at the same size and against the LAPACK golden
+    (tests/golden/golden_N65536.json: direct distances only, the expansion form does not fit the generator's host).
+    The real 8-GPU run is the driver's (bench.py --gpus 8, `n65536` sub-object)."""
+    N = 65536
+    z = golden(N)["direct"]
+    X, y = synth.drillholes(N)
+    g4 = gpak.Gpak(devices=[0, 0, 0, 0])
+    try:
+        g4.set_train(X, y)
+        g4.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        nlz4 = g4.logLikelihood()
+        q4, s4, l4 = g4.nlz_terms()
+        a4 = g4.solve_alpha()
+    finally:
+        g4.close()
+    gp.set_train(X, y)
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+    nlz1 = gp.logLikelihood()
+    q1, s1, l1 = gp.nlz_terms()
+    a1 = gp.solve_alpha()
+    idx = np.array(golden(N)["alpha_idx"])
+    print(f"\nN=65536: 4 ranks vs 1 context nlz {abs(nlz4 - nlz1) / abs(nlz1):.2e}, alpha {rel(a4, a1):.2e}; "
+          f"vs LAPACK golden: nlz {abs(nlz4 - z['nlz']) / abs(z['nlz']):.2e} / {abs(nlz1 - z['nlz']) / abs(z['nlz']):.2e}, "
+          f"logdet {abs(l4 - z['logdet']) / abs(z['logdet']):.2e}, alpha {rel(a4[idx], z['alpha_samples']):.2e}")
+    assert abs(nlz4 - nlz1) <= 1e-12 * abs(nlz1) and rel(a4, a1) <= 1e-9
+    for nlz, q, s, l, a in ((nlz4, q4, s4, l4, a4), (nlz1, q1, s1, l1, a1)):
+        assert abs(nlz - z["nlz"]) <= 1e-9 * abs(z["nlz"])
+        assert abs(l - z["logdet"]) <= 1e-10 * abs(z["logdet"])
+        assert abs(q - z["quad"]) <= 1e-9 * abs(z["quad"]) and abs(s - z["sumlp"]) <= 1e-9 * abs(z["sumlp"])
+        assert rel(a[idx], z["alpha_samples"]) <= 1e-8
+    gp.set_train(X[:64], y[:64])
