@@ -441,22 +441,26 @@ int gpak_dist_selfcheck(gpak_dist *h, int *flags_out) {
     for (int i = 0; i < n; i++) host[i] = 1.0 + i;
     if (E.upload(E.self, h->s_bulk, a, host.data(), sizeof(double) * n) != GPAK_OK) ok = 0;
     if (ok && E.vec_scale(h->s_bulk, n, a, 2.0, a) != GPAK_OK) ok = 0;
-    // communication stream, concurrently: broadcast from every root, then an all-reduce
-    for (int root = 0; ok && root < h->P; root++) {
+    // communication stream, concurrently: broadcast from every root, then an all-reduce.  Every rank issues the SAME
+    // sequence of collectives whatever it has seen so far (a rank that stopped early would hang the others); only a
+    // failing CALL ends the sequence, and then every later call on this rank fails the same way.
+    bool call_failed = !ok;
+    for (int root = 0; !call_failed && root < h->P; root++) {
       for (int i = 0; i < n; i++) host[i] = (h->rank == root) ? 1000.0 * (root + 1) + i : -1.0;
-      if (E.upload(E.self, h->s_comm, b, host.data(), sizeof(double) * n) != GPAK_OK) { ok = 0; break; }
-      if (T.bcast(T.self, h->s_comm, b, n, root) != GPAK_OK) { ok = 0; break; }
-      if (E.download(E.self, h->s_comm, back.data(), b, sizeof(double) * n) != GPAK_OK) { ok = 0; break; }
+      if (E.upload(E.self, h->s_comm, b, host.data(), sizeof(double) * n) != GPAK_OK ||
+          T.bcast(T.self, h->s_comm, b, n, root) != GPAK_OK ||
+          E.download(E.self, h->s_comm, back.data(), b, sizeof(double) * n) != GPAK_OK) { call_failed = true; break; }
       for (int i = 0; i < n; i++) if (back[i] != 1000.0 * (root + 1) + i) { ok = 0; break; }
     }
-    if (ok) {
+    if (!call_failed) {
       for (int i = 0; i < n; i++) host[i] = (double)(h->rank + 1);
       if (E.upload(E.self, h->s_comm, b, host.data(), sizeof(double) * n) != GPAK_OK ||
           T.allreduce_sum(T.self, h->s_comm, b, n) != GPAK_OK ||
-          E.download(E.self, h->s_comm, back.data(), b, sizeof(double) * n) != GPAK_OK) ok = 0;
+          E.download(E.self, h->s_comm, back.data(), b, sizeof(double) * n) != GPAK_OK) call_failed = true;
       const double want = 0.5 * h->P * (h->P + 1);
-      for (int i = 0; ok && i < n; i++) if (back[i] != want) ok = 0;
+      for (int i = 0; !call_failed && i < n; i++) if (back[i] != want) { ok = 0; break; }
     }
+    if (call_failed) ok = 0;
     if (ok) {
       if (E.download(E.self, h->s_bulk, back.data(), a, sizeof(double) * n) != GPAK_OK) ok = 0;
       for (int i = 0; ok && i < n; i++) if (back[i] != 2.0 * (1.0 + i)) ok = 0;

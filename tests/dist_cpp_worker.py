@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--sn2", type=float, default=None)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--grad", type=int, default=0)
+    ap.add_argument("--corrupt", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,7 +38,7 @@ def main():
         gp = gd.DistRank(a.rank, a.world, device=0, transport=tr)
     else:
         from np_dist_engine import GlooTransport, NumpyDistEngine
-        eng, tr = NumpyDistEngine(), GlooTransport()
+        eng, tr = NumpyDistEngine(), GlooTransport(corrupt_first=a.corrupt)
         gp = gd.DistRank(a.rank, a.world, engine=eng, transport=tr)
     X, y = synth.drillholes(a.n)
     gp.set_train(X, y, nb=a.nb)

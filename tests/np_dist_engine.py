@@ -237,13 +237,20 @@ class NumpyDistEngine:
 class GlooTransport:
     """gpak_dist_transport over a gloo group for HOST buffers (the NumPy engine's memory)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, corrupt_first=0):
+        """corrupt_first: flip one word of the first k broadcasts AFTER delivery (on the receivers) -- what a broken
+        side-stream collective would look like to the start-up self-check."""
         import torch.distributed as dist
         self.bytes = 0
+        self.n_bcast = 0
 
         def bcast(_s, st, buf, count, root):
             self.bytes += 8 * int(count)
-            dist.broadcast(_t(buf, count), src=root, group=group)
+            t = _t(buf, count)
+            dist.broadcast(t, src=root, group=group)
+            self.n_bcast += 1
+            if self.n_bcast <= corrupt_first and dist.get_rank(group) != root:
+                t[int(count) // 2] += 1.0
             return 0
 
         def ar_sum(_s, st, buf, count):

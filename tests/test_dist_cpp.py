@@ -32,18 +32,19 @@ def free_port():
     return p
 
 
-def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0):
+def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0, corrupt=0, env=None):
     port = free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
         for r in range(world):
             cmd = [sys.executable, os.path.join(HERE, "dist_cpp_worker.py"), "--rank", str(r), "--world", str(world),
                    "--port", str(port), "--n", str(n), "--nb", str(nb), "--engine", engine, "--mode", str(mode),
-                   "--steps", str(steps), "--grad", str(grad), "--out", os.path.join(d, f"r{r}.json")]
+                   "--steps", str(steps), "--grad", str(grad), "--corrupt", str(corrupt), "--out",
+                   os.path.join(d, f"r{r}.json")]
             if sn2 is not None:
                 cmd += ["--sn2", str(sn2)]
-            env = dict(os.environ, OMP_NUM_THREADS="2")
-            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+            penv = dict(os.environ, OMP_NUM_THREADS="2", **(env or {}))
+            procs.append(subprocess.Popen(cmd, env=penv, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
         for p, o in zip(procs, outs):
             assert p.returncode == 0, o[-3000:]
@@ -104,6 +105,29 @@ def test_cpp_schedule_repeated_steps_and_expansion_mode(orc):
         assert abs(r["nlz"] - info.nlz) <= 1e-6 * abs(info.nlz)     # expansion mode: cancellation noise
 
 
+def test_selfcheck_failure_switches_every_rank_to_plain_streams(orc):
+    """A collective that delivers wrong data during the start-up self-check (here: the first broadcast, corrupted on the
+    receivers) must be caught BEFORE the first step: every rank -- also the root, which saw nothing wrong -- falls
+    back to plain streams with the collectives in line (flags 1|2), re-checks, and then computes the right answer."""
+    res = run_world(3, 700, 128, corrupt=1)
+    info, alpha = oracle_ref(orc, 700)
+    for r in res:
+        assert r["stats"]["flags"] == 3, r["stats"]
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+        # in-line collectives: every factor / update of the panel chain still sits on the panel stream, and there is
+        # no separate communication stream any more
+        assert all(st == 101 for op, J, st in r["calls"] if op in ("factor", "update_block"))
+    ok = run_world(3, 700, 128)
+    assert all(r["stats"]["flags"] == 0 for r in ok)
+
+
+def test_plain_stream_mode_can_be_forced(orc):
+    res = run_world(2, 600, 256, env={"GPAK_DIST_PLAIN_STREAMS": "1"}, grad=1)
+    info, alpha = oracle_ref(orc, 600)
+    for r in res:
+        assert r["stats"]["flags"] == 3 and abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+
+
 def test_cpp_schedule_chol_fail_is_nan_on_every_rank():
     res = run_world(2, 300, 128, sn2=-0.5)
     assert all(r["nlz"] != r["nlz"] for r in res)                   # NaN (GP_Utils.cpp:1145-1146)
@@ -132,6 +156,18 @@ def test_cpp_distributed_gradient_hip_engine_matches_oracle(orc, world, n, nb):
     go = orc.grad_ref(X, y, K, L, alpha, e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, 1)
     for r in res:
         assert np.abs(np.array(r["grad"]) - go).max() <= 1e-8 * np.abs(go).max(), (r["rank"], r["grad"], go.tolist())
+
+
+@pytest.mark.gpu
+def test_cpp_schedule_hip_engine_plain_stream_fallback(orc):
+    """The fallback the self-check selects (ordinary bulk stream, collectives in line on the panel stream) with the HIP
+    engine: same numbers."""
+    res = run_world(3, 2500, 256, engine="hip", env={"GPAK_DIST_PLAIN_STREAMS": "1"}, grad=1, steps=2)
+    info, alpha = oracle_ref(orc, 2500)
+    for r in res:
+        assert r["stats"]["flags"] == 3
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
 
 
 @pytest.mark.gpu
