@@ -588,16 +588,18 @@ static int produce(gpak_dist *h, int b, void **done) {
       double *sub = h->blk(b) + (size_t)s * GPAK_TILE * ld;
       DCHK(E.factor_panel(h->s_panel, sub, ld, Np, J + s * GPAK_TILE, GPAK_TILE,
                           h->invs[b] + (size_t)s * 2 * GPAK_TILE * GPAK_TILE, h->info));
-      const int rem = W - (s + 1) * GPAK_TILE;
-      if (rem > 0)   // the rest of the owner's own block column
-        DCHK(E.update_block(h->s_panel, sub, ld, 0, GPAK_TILE, h->blk(b) + (size_t)(s + 1) * GPAK_TILE * ld, ld, Np,
-                            J + (s + 1) * GPAK_TILE, rem));
-      DCHK(E.pack(h->s_panel, sub, ld, J, rows, GPAK_TILE, chunk));
+      // the pack runs on the communication stream, in front of the broadcast it feeds: the sub-panel is final once
+      // it is solved, and the panel chain goes straight on with the rest of the owner's own block column
       if (h->s_comm != h->s_panel) {
         void *e = h->sync_event();
         DCHK(E.event_record(E.self, e, h->s_panel));
         DCHK(E.stream_wait_event(E.self, h->s_comm, e));
       }
+      DCHK(E.pack(h->s_comm, sub, ld, J, rows, GPAK_TILE, chunk));
+      const int rem = W - (s + 1) * GPAK_TILE;
+      if (rem > 0)   // the rest of the owner's own block column
+        DCHK(E.update_block(h->s_panel, sub, ld, 0, GPAK_TILE, h->blk(b) + (size_t)(s + 1) * GPAK_TILE * ld, ld, Np,
+                            J + (s + 1) * GPAK_TILE, rem));
     }
     size_t c0 = 0;
     if (h->profile && h->P > 1) c0 = h->time_event(h->s_comm);
