@@ -132,15 +132,20 @@ def _pmc(tag, N):
     if not os.path.exists(path):
         return None
     z = json.load(open(path))
-    k = "void gpak_gemm_nt_f64_rs<4, 2, true>"
     out = {"source": os.path.relpath(path, ROOT)}
+
+    def pick(section):   # the bulk trailing update: gpak_gemm_nt_f64_rs<4, 2, true[, false]>
+        for name, v in z.get(section, {}).items():
+            if name.startswith("void gpak_gemm_nt_f64_rs<4, 2, true"):
+                return v
+        raise KeyError(section)
     try:
-        f, w = z["FETCH_SIZE"][k]["FETCH_SIZE"], z["WRITE_SIZE"][k]["WRITE_SIZE"]
+        f, w = pick("FETCH_SIZE")["FETCH_SIZE"], pick("WRITE_SIZE")["WRITE_SIZE"]
         out["traffic"] = (2.0 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024.0
     except KeyError:
         out["traffic"] = None
     try:
-        sq = z["SQ"][k]
+        sq = pick("SQ")
         out["mfma_busy_cycles_per_launch"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / sq["SQ_VALU_MFMA_BUSY_CYCLES"]["dispatches"]
         out["grbm_gui_active_per_launch"] = sq["GRBM_GUI_ACTIVE"]["sum"] / sq["GRBM_GUI_ACTIVE"]["dispatches"]
     except KeyError:
