@@ -40,7 +40,8 @@ def main():
         from np_dist_engine import GlooTransport, NumpyDistEngine
         eng, tr = NumpyDistEngine(), GlooTransport(corrupt_first=a.corrupt)
         gp = gd.DistRank(a.rank, a.world, engine=eng, transport=tr)
-    X, y = synth.drillholes(a.n)
+    X, y = synth.drillholes(max(a.n, 4))
+    X, y = X[:a.n].copy(order="F"), y[:a.n].copy()
     gp.set_train(X, y, nb=a.nb)
     sn2 = synth.DEFAULT_SN2 if a.sn2 is None else a.sn2
     res = {"rank": a.rank}

@@ -98,6 +98,23 @@ def test_cpp_distributed_gradient_over_gloo_matches_oracle(orc, world, n, nb, mo
     assert all(r["grad"] == res[0]["grad"] for r in res)            # bit-identical on every rank
 
 
+@pytest.mark.parametrize("world,n,nb", [(4, 300, 128), (3, 130, 128), (4, 500, 512), (2, 1, 128)])
+def test_ranks_that_own_nothing(orc, world, n, nb):
+    """Fewer block columns (and 128-row blocks) than ranks: the idle ranks still take part in every collective and
+    report the same nlZ / alpha / gradient."""
+    res = run_world(world, n, nb, grad=1)
+    X, y = synth.drillholes(max(n, 4))
+    X, y = np.asfortranarray(X[:n]), y[:n].copy()
+    e = np.array(synth.DEFAULT_EXPANS)
+    K = orc.gram(X, X, e, synth.DEFAULT_BIAS, 1)
+    info, alpha, L = orc.nlz_lean(K, y, synth.DEFAULT_SN2)
+    go = orc.grad_ref(X, y, K, L, alpha, e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, 1)
+    for r in res:
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * max(1.0, abs(info.nlz))
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+        assert np.abs(np.array(r["grad"]) - go).max() <= 1e-8 * max(1.0, np.abs(go).max())
+
+
 def test_cpp_schedule_repeated_steps_and_expansion_mode(orc):
     res = run_world(3, 900, 256, steps=3, mode=0)
     info, alpha = oracle_ref(orc, 900, mode=0)
@@ -146,7 +163,7 @@ def test_cpp_schedule_hip_engine_matches_oracle(orc, world, n, nb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,nb", [(1, 1000, 256), (2, 1500, 256), (3, 2500, 512), (4, 5000, 512)])
+@pytest.mark.parametrize("world,n,nb", [(1, 1000, 256), (2, 1500, 256), (3, 2500, 512), (4, 5000, 512), (4, 300, 128)])
 def test_cpp_distributed_gradient_hip_engine_matches_oracle(orc, world, n, nb):
     res = run_world(world, n, nb, engine="hip", grad=1)
     X, y = synth.drillholes(n)
