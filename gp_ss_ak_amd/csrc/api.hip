@@ -158,6 +158,7 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
   if (const char *pe = getenv("GPAK_FWD_IN_FACTOR")) ctx->fwd_in_factor = atoi(pe) != 0;
   if (const char *pe = getenv("GPAK_LOOKAHEAD")) ctx->lookahead = atoi(pe) != 0;   // diagnostics: 0 = one stream
+  if (const char *pe = getenv("GPAK_LOOKAHEAD")) ctx->lookahead = atoi(pe) != 0;   // diagnostics: 0 = one stream
   const char *nb = getenv("GPAK_NB_OUTER");
   if (nb) ctx->nb_outer = atoi(nb);
   *out = ctx;
