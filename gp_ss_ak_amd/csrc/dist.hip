@@ -151,6 +151,7 @@ struct Rccl {
   std::string err;
   bool load() {
     if (lib) return true;
+    if (getenv("GPAK_RCCL_DISABLE") && atoi(getenv("GPAK_RCCL_DISABLE"))) { err = "librccl disabled (GPAK_RCCL_DISABLE)"; return false; }
     const char *names[] = {getenv("GPAK_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
       if (!n || !*n) continue;

@@ -234,7 +234,7 @@ void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, in
 // fixed order (deterministic).
 // ---------------------------------------------------------------------------------------
 #define KMV_CHUNK 256
-#define KMV_COLS 2   // target columns per thread: every LDS read of a source point serves two evaluations
+#define KMV_COLS 2   // target columns per thread: every LDS read of a source point serves two evaluations (4: no faster)
 template <int NT>
 __global__ __launch_bounds__(256) void gpak_kmatvec_part_f64(const double *__restrict__ P, int capP, int nP, int p_off,
                                                               const double *__restrict__ w, int per_split,

@@ -297,7 +297,7 @@ def bench(args):
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     # host-side control plane only (unique id, barriers, max over ranks): gloo.  The data path -- every panel
     # broadcast and all-reduce -- is RCCL inside libgpak_hip.so.
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     # GPAK_DIST_TRANSPORT=staged / GPAK_DIST_DEVICE exist for the tests: they rehearse this exact entry point with
     # several ranks on the ONE GPU of a test box (RCCL refuses two ranks per GPU; gloo stages the collectives)
     staged = os.environ.get("GPAK_DIST_TRANSPORT", "rccl") == "staged"
@@ -312,6 +312,31 @@ def bench(args):
         dist.broadcast_object_list(ids, src=0)
         return DistRank(rank, world, device=local, rccl_id=ids[0])
 
+    # start-up probe: create a rank (dlopen librccl, ncclCommInitRank) and run the library's self-check once.  If that
+    # fails -- on ANY rank: the verdict is min-reduced over the control plane -- the round-1 Python schedule over
+    # torch's own NCCL process group takes over, and the line says so; a failure later than this is a failure.
+    ok, why = 1, ""
+    try:
+        probe = make_rank()
+        probe.selfcheck()
+        probe.close()
+    except Exception as e:   # noqa: BLE001 -- anything at start-up selects the fallback
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0 and not staged:
+        import sys
+        print(f"[gpak rank {rank}] C++ multi-GPU start-up failed ({why or 'on another rank'}); falling back to the Python "
+              f"schedule over torch.distributed NCCL", file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        from . import multigpu
+        out = multigpu.bench(args)
+        if out is not None:
+            out["fallback"] = "round-1 Python schedule over torch.distributed NCCL: the C++ RCCL start-up failed" + (
+                f" ({why})" if why else "")
+        return out
+    if int(flag.item()) == 0:
+        raise RuntimeError(f"distributed start-up failed: {why}")
     res = _one_size(args, args.n, dist, rank, world, local, make_rank, args.steps, args.warmup, bench_mod)
     extra = None
     if args.n != 65536 and not args.no_n65536:

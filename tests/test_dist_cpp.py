@@ -250,6 +250,17 @@ def test_bench_distributed_entry_point_over_rccl_one_rank():
 
 
 @pytest.mark.gpu
+def test_bench_falls_back_to_the_python_schedule_when_rccl_cannot_start():
+    """If the library's RCCL start-up fails (here: librccl made unloadable), every rank learns it through the control
+    plane before the first step and the round-1 Python schedule over torch.distributed's NCCL group takes over; the
+    line carries a `fallback` note and the same nlZ."""
+    d = _bench(1, {"GPAK_FORCE_DIST": "1", "GPAK_DIST_RCCL_WORLD1": "1", "GPAK_RCCL_DISABLE": "1"}, 4096)
+    assert "fallback" in d and d["n_gpus"] == 1 and d["value"] > 0
+    s = _single(4096)
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_distributed_entry_point_with_several_ranks(world):
     """bench.py --gpus N as the driver launches it, N ranks rehearsed on this box's one GPU (collectives staged
