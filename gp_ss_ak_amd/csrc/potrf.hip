@@ -54,14 +54,24 @@ __device__ __forceinline__ int gpak_tix(int rt, int ct, int i, int k) {
 //   inv    : 2 x (128x128) doubles: inv(L) then inv(L)^T, column-major ld 128
 //   col0   : global column of the block (for the not-positive-definite report)
 //   info   : atomicMin of the first failing column (1-based)
-__global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv,
+#ifdef GPAK_POTRF_TIMING
+__device__ long long gpak_potrf_dbg[64];
+#define GPAK_TS(i_) do { if (t == 0) gpak_potrf_dbg[i_] = (long long)__builtin_readcyclecounter(); } while (0)
+extern "C" int gpak_dev_potrf_timing(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gpak_potrf_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+}
+#else
+#define GPAK_TS(i_) do { } while (0)
+#endif
+__global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv,
                                                           int col0, int *info, int zero_inv) {
   __shared__ double T[36 * 256];
   __shared__ double dd[8][16];
   // this workgroup is the serial link of the panel chain and shares its CU with two trailing-update
   // waves per SIMD: let its instructions win the issue arbitration
-  __builtin_amdgcn_s_setprio(3);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  // wave 0 carries the serial chain (the diagonal blocks): it outranks its own helpers, which outrank everybody else
+  if (w == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
   const int l15 = lane & 15, l4 = lane >> 4;
   double *invT = inv + PB * PB;
 
@@ -70,101 +80,154 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
     return j > k ? T[gpak_tix(r, r, k, j)] : (j == k ? dd[r][j] : 0.0);
   };
 
-  // ---- load: 32 row pairs per thread, 16-B accesses, all loads of a batch in flight together
-#pragma unroll 8
-  for (int it = 0; it < 32; it++) {
-    const int e = t + 256 * it, r = (e & 63) * 2, c = e >> 6;
+  GPAK_TS(0);
+  // ---- load: straight into the LDS image by LDS-DMA (global_load_lds_dwordx4), no register staging, everything in
+  // flight at once.  One wave instruction moves 1 KiB = columns 8h..8h+7 of one 16x16 tile: lane l brings rows
+  // 2(l&7), 2(l&7)+1 of column 8h + (l>>3); 72 such pieces, 9 per wave.
+  {
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int li = 2 * (lane & 7), lk = lane >> 3;
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+      const int c = wu + 8 * p, slot = c >> 1, half = c & 1;
+      int rt = 0, rem = slot;
+      while (rem > rt) { rem -= rt + 1; rt++; }   // slot -> (rt, ct = rem), scalar
+      const double *src = A + (16 * rt + li) + (size_t)(16 * rem + 8 * half + lk) * ld;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&T[(slot << 8) + (half << 7)], 16, 0, 0);
+    }
+  }
+  if (zero_inv) {
+    // the caller's inverse buffers are not known to be zero outside the triangles written at the end (the context's
+    // own are zeroed once in gpak_set_train)
     const double2 z = make_double2(0.0, 0.0);
-    // zero_inv: the caller's inverse buffers are not known to be zero outside the triangles written at the
-    // end (the context's own are zeroed once in gpak_set_train: these 128 KiB of stores otherwise sit in
-    // front of every batch's vmcnt wait)
-    if ((r >> 4) >= (c >> 4)) {
-      const double2 v = *reinterpret_cast<const double2 *>(A + r + (size_t)c * ld);
-      *reinterpret_cast<double2 *>(&T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)]) = v;
-      if (zero_inv && (r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;  // inv^T is upper
-    } else if (zero_inv) {
-      *reinterpret_cast<double2 *>(inv + r + c * PB) = z;                            // inv is lower
+#pragma unroll 8
+    for (int it = 0; it < 16; it++) {
+      const int e = t + 512 * it, r = (e & 63) * 2, c = e >> 6;
+      if ((r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;        // inv^T is upper
+      else if ((r >> 4) < (c >> 4)) *reinterpret_cast<double2 *>(inv + r + c * PB) = z;   // inv is lower
     }
   }
   __syncthreads();
 
-  // diagonal block kb: factor + invert (wave 0 only; see the header comment)
-  auto diag_block = [&](int kb) {
-    double a[16];
+  // diagonal block kb: factor + invert (wave 0 only), ON THE MATRIX PIPE.  The 16x16 block sits in ONE f64 accumulator
+  // (row = (lane>>4) + 4*reg, col = lane&15) in UPPER form, a second accumulator W starts as the identity.  Pivot r:
+  // row r (register r/4, lanes with lane>>4 == r%4) is scaled by d^-1/2 (v_rsq_f64 + two Newton steps, no divisions)
+  // and, masked to those lanes, IS the A and the B operand of the rank-1 update S -= u u^T (K = 4 with one live k):
+  // no element moves between lanes.  The same row operations applied to W turn the identity into L^-1 (Cholesky as
+  // Gaussian elimination on [D | I]), so the block's inverse costs one more MFMA per pivot instead of the separate
+  // substitution it needed before.  ~170 instead of ~590 cycles per pivot.
+  // upd >= 0: the block first receives the update of panel column `upd`, C -= P P^T with P = tile (kb, upd) -- the
+  // "tile 0" of the trailing update, done here in registers so that the tile never goes back through LDS in between
+  auto diag_block = [&](int kb, int upd) {
+    d4 S, Wm;
+    double pa[4];
+    if (upd >= 0) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const double v = T[gpak_tix(kb, kb, l15, k)];
-      a[k] = (l4 == 1) ? (k == l15 ? 1.0 : 0.0) : v;   // lanes 16..31: identity rows
+      for (int s4 = 0; s4 < 4; s4++) pa[s4] = T[gpak_tix(kb, upd, l15, 4 * s4 + l4)];
     }
-    int bad = 16;   // first non-positive pivot of this block (branch-free: the 16 pivots stay ONE basic block,
-                    // so the scheduler can fill the rsq/Newton latency of pivot j+1 with the updates of pivot j)
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      double d = gpak_rdlane(a[j], j);
-      const bool ok = d > 0.0;
-      bad = (!ok && bad == 16) ? j : bad;
-      d = ok ? d : 1.0;
-      double r = __builtin_amdgcn_rsq(d);
-      double h = d * r;
-      double e = fma(-h, r, 1.0);
-      r = fma(r * 0.5, e, r);
-      h = d * r;
-      e = fma(-h, r, 1.0);
-      r = fma(r * 0.5, e, r);       // r = d^-1/2
-      double ljj = d * r;
-      ljj = fma(fma(-ljj, ljj, d) * 0.5, r, ljj);  // sqrt(d), one correction
-      a[j] = (lane == j) ? ljj : a[j] * r;
+    for (int q = 0; q < 4; q++) {
+      const int row = l4 + 4 * q;
+      S[q] = (l15 >= row) ? T[gpak_tix(kb, kb, l15, row)] : 0.0;   // S[row][col] = A[col][row]: the stored lower part
+      Wm[q] = (l15 == row) ? 1.0 : 0.0;
+    }
+    if (upd >= 0) {
 #pragma unroll
-      for (int k = j + 1; k < 16; k++) {
-        const double lk = gpak_rdlane(a[j], k);
-        a[k] = fma(-a[j], lk, a[k]);
+      for (int s4 = 0; s4 < 4; s4++) S = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pa[s4], S, 0, 0, 0);
+    }
+    int bad = 16;   // first non-positive pivot of this block
+    // software pipeline: (g, ri) = (sqrt, 1/sqrt) of pivot r are computed on the vector pipe while the matrix pipe
+    // still applies pivot r-1.  Uf / Wf collect the finished rows (the accumulators keep the unscaled ones: the A
+    // operand of an update is zero on its own row, so finished rows are never touched again)
+    d4 Uf = (d4){0.0, 0.0, 0.0, 0.0}, Wf = (d4){0.0, 0.0, 0.0, 0.0};
+    double g, ri;
+    auto root = [&](double dv, int r) {   // coupled (Goldschmidt) iteration: g -> sqrt(d), h -> 0.5 / sqrt(d)
+      const bool ok = dv > 0.0;
+      bad = (!ok && bad == 16) ? r : bad;
+      dv = ok ? dv : 1.0;
+      const double y = __builtin_amdgcn_rsq(dv);
+      double gg = dv * y, h = 0.5 * y;
+      double e = fma(-h, gg, 0.5);
+      gg = fma(gg, e, gg);
+      h = fma(h, e, h);
+      e = fma(-h, gg, 0.5);
+      g = fma(gg, e, gg);
+      h = fma(h, e, h);
+      ri = h + h;
+    };
+    root(gpak_rdlane(S[0], 0), 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int q = r >> 2, k4 = r & 3;
+      const bool myrow = l4 == k4;
+      double mu = S[q] * ri;
+      mu = (l15 == r) ? g : mu;
+      mu = (myrow && l15 >= r) ? mu : 0.0;              // U[r][c], c >= r, on the lanes of row r; 0 elsewhere
+      const double ma = (l15 == r) ? 0.0 : mu;          // A operand: zero on row r itself
+      const double mw = myrow ? Wm[q] * ri : 0.0;       // (L^-1)[r][c]
+      Uf[q] = myrow ? mu : Uf[q];
+      Wf[q] = myrow ? mw : Wf[q];
+      double sn = 0.0;
+      if (r < 15) sn = gpak_rdlane(S[(r + 1) >> 2], (r + 1) + 16 * ((r + 1) & 3));   // S[r+1][r+1] before this update
+      __builtin_amdgcn_sched_barrier(0);
+      if (r < 15) {
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-ma, mu, S, 0, 0, 0);     // S[i][c] -= U[r][i] U[r][c], i > r
+        Wm = __builtin_amdgcn_mfma_f64_16x16x4f64(-ma, mw, Wm, 0, 0, 0);   // W[i][c] -= U[r][i] W[r][c], i > r
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (r < 15) {
+        const double un = gpak_rdlane(mu, (r + 1) + 16 * k4);               // U[r][r+1]
+        root(fma(-un, un, sn), r + 1);                                      // the next pivot, beside the MFMAs
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    S = Uf; Wm = Wf;
     if (bad < 16 && lane == 0) atomicMin(info, col0 + 16 * kb + bad + 1);
-    if (l4 == 0) {
 #pragma unroll
-      for (int k = 0; k < 16; k++)
-        if (k <= l15) T[gpak_tix(kb, kb, l15, k)] = a[k];           // L, lower part
-    } else if (l4 == 1) {
-      // identity row c = l15 became row c of L^-T: a[k] = inv(L)[k][c]; park it transposed in the
-      // strictly-upper part of the tile, its diagonal in dd[]
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        if (k > l15) T[gpak_tix(kb, kb, l15, k)] = a[k];
-        if (k == l15) dd[kb][k] = a[k];
-      }
+    for (int q = 0; q < 4; q++) {
+      const int k = l4 + 4 * q;                       // S holds U[k][l15] = L[l15][k]; Wm holds (L^-1)[k][l15]
+      if (l15 >= k) T[gpak_tix(kb, kb, l15, k)] = S[q];            // L, lower part
+      // the inverse is parked (transposed) in the strictly-upper part of the tile, its diagonal in dd[]
+      if (k > l15) T[gpak_tix(kb, kb, l15, k)] = Wm[q];
+      if (k == l15) dd[kb][k] = Wm[q];
     }
   };
 
-  if (w == 0) diag_block(0);
+  GPAK_TS(1);
+  if (w == 0) diag_block(0, -1);
+  GPAK_TS(2);
   __syncthreads();
 
   for (int kb = 0; kb < 7; kb++) {
     const int nt = 7 - kb;  // 16-row tiles below the diagonal block
-    // ---- panel tiles: P := P * inv(D)^T  (a tile depends only on itself: no barrier inside)
+    // ---- panel tiles: P := P * inv(D)^T  (a tile depends only on itself: no barrier inside); one tile per wave,
+    // all operands requested before the first MFMA
     {
-      d4 acc[2];
-      int rt[2];
+      const int rt = kb + 1 + w;
+      if (rt < 8) {
+        double pa[4], xb[4];
 #pragma unroll
-      for (int u = 0; u < 2; u++) { rt[u] = kb + 1 + w + 4 * u; acc[u] = (d4){0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const double xb = dinv(kb, l15, 4 * s + l4);  // B[k][j] = inv(D)[j][k]
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-          if (rt[u] < 8) {
-            const double pa = T[gpak_tix(rt[u], kb, l15, 4 * s + l4)];
-            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, xb, acc[u], 0, 0, 0);
-          }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-        if (rt[u] < 8) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) T[gpak_tix(rt[u], kb, l4 + 4 * r, l15)] = acc[u][r];
+        for (int s = 0; s < 4; s++) {
+          xb[s] = dinv(kb, l15, 4 * s + l4);   // B[k][j] = inv(D)[j][k]
+          pa[s] = T[gpak_tix(rt, kb, l15, 4 * s + l4)];
         }
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};   // two chains of two (see the inverse below)
+#pragma unroll
+        // operand roles swapped: the accumulator holds P^T (row of P = lane&15), so its four registers go back to
+        // LDS as 16 consecutive doubles per lane group instead of a 128-B stride (8-way bank conflict)
+        for (int s = 0; s < 4; s += 2) {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[s], pa[s], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[s + 1], pa[s + 1], acc1, 0, 0, 0);
+        }
+        acc += acc1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[gpak_tix(rt, kb, l15, l4 + 4 * r)] = acc[r];
+      }
     }
     __syncthreads();
+    GPAK_TS(3 + 4 * kb);
     // ---- trailing update of the lower tiles C(ti,tj) -= P_ti P_tj^T.  Tile 0 is the next
     // diagonal tile: wave 0 updates it and goes straight on to factor it; waves 1..3 share the
     // other tiles, four independent tiles in flight at a time.
@@ -183,7 +246,7 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
           rti[u] = kb + 1 + ti; rtj[u] = kb + 1 + rem;
           if (ok[u]) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[u][r] = T[gpak_tix(rti[u], rtj[u], l4 + 4 * r, l15)];
+            for (int r = 0; r < 4; r++) acc[u][r] = T[gpak_tix(rti[u], rtj[u], l15, l4 + 4 * r)];   // C^T: conflict-free
           }
         }
 #pragma unroll
@@ -193,30 +256,33 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
             if (ok[u]) {
               const double pa = -T[gpak_tix(rti[u], kb, l15, 4 * s + l4)];
               const double pb = T[gpak_tix(rtj[u], kb, l15, 4 * s + l4)];
-              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc[u], 0, 0, 0);
+              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb, pa, acc[u], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
           if (ok[u]) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) T[gpak_tix(rti[u], rtj[u], l4 + 4 * r, l15)] = acc[u][r];
+            for (int r = 0; r < 4; r++) T[gpak_tix(rti[u], rtj[u], l15, l4 + 4 * r)] = acc[u][r];
           }
       }
     };
     if (w == 0) {
-      trailing_tiles(0, ntile);       // just tile 0 = (kb+1, kb+1)
-      diag_block(kb + 1);
+      GPAK_TS(4 + 4 * kb);
+      diag_block(kb + 1, kb);         // tile 0 = (kb+1, kb+1): update and factor in registers
+      GPAK_TS(5 + 4 * kb);
     } else {
-      trailing_tiles(w, 3);           // tiles 1.. in steps of 3 waves
+      trailing_tiles(w, 7);           // tiles 1.. in steps of 7 waves
     }
     __syncthreads();
+    GPAK_TS(6 + 4 * kb);
   }
+  GPAK_TS(32);
 
   // L out (upper part of the block zeroed so the stored matrix is cleanly lower)
 #pragma unroll 8
-  for (int it = 0; it < 32; it++) {
-    const int e = t + 256 * it, r = (e & 63) * 2, c = e >> 6;
+  for (int it = 0; it < 16; it++) {
+    const int e = t + 512 * it, r = (e & 63) * 2, c = e >> 6;
     double2 v = make_double2(0.0, 0.0);
     if ((r >> 4) >= (c >> 4)) {
       v = *reinterpret_cast<const double2 *>(&T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)]);
@@ -226,11 +292,13 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
     *reinterpret_cast<double2 *>(A + r + (size_t)c * ld) = v;
   }
 
+  GPAK_TS(33);
   // 128x128 inverse, block column c per wave pass: X_cc = inv(D_c),
   // X_rc = -inv(D_r) * sum_{k=c..r-1} L_rk X_kc
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-    const int c = pass ? 7 - w : w;
+  {
+    // eight waves, one block column each; waves w and w+4 share a SIMD (and its matrix pipe): pair the long columns
+    // with the short ones (0,7) (1,6) (2,5) (3,4)
+    const int c = w < 4 ? w : 11 - w;
     d4 Xt[8];
 #pragma unroll
     for (int s = 0; s < 4; s++) Xt[0][s] = dinv(c, l4 + 4 * s, l15);
@@ -244,21 +312,33 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
     for (int rr = 1; rr < 8; rr++) {
       if (c + rr <= 7) {
         const int r = c + rr;
-        d4 G = (d4){0.0, 0.0, 0.0, 0.0};
+        // every LDS operand of this block row is requested before the first MFMA (the chain is 4 rr + 4 dependent
+        // MFMAs: with a read in front of each one the LDS latency, not the matrix pipe, set the pace)
+        double la[7][4], da[4];
 #pragma unroll
-        for (int m = 0; m < rr; m++) {
+        for (int m = 0; m < rr; m++)
 #pragma unroll
-          for (int s = 0; s < 4; s++) {
-            double la = T[gpak_tix(r, c + m, l15, 4 * s + l4)];
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(la, Xt[m][s], G, 0, 0, 0);
+          for (int s = 0; s < 4; s++) la[m][s] = T[gpak_tix(r, c + m, l15, 4 * s + l4)];
+#pragma unroll
+        for (int s = 0; s < 4; s++) da[s] = -dinv(r, l15, 4 * s + l4);
+        // two interleaved accumulator chains: a DEPENDENT f64 MFMA issues every ~130 cycles, an independent one
+        // every 64
+        d4 G = (d4){0.0, 0.0, 0.0, 0.0}, G1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < rr; m++)
+#pragma unroll
+          for (int s = 0; s < 4; s += 2) {
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(la[m][s], Xt[m][s], G, 0, 0, 0);
+            G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[m][s + 1], Xt[m][s + 1], G1, 0, 0, 0);
           }
-        }
-        d4 Xn = (d4){0.0, 0.0, 0.0, 0.0};
+        G += G1;
+        d4 Xn = (d4){0.0, 0.0, 0.0, 0.0}, Xn1 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          double da = -dinv(r, l15, 4 * s + l4);
-          Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(da, G[s], Xn, 0, 0, 0);
+        for (int s = 0; s < 4; s += 2) {
+          Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(da[s], G[s], Xn, 0, 0, 0);
+          Xn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[s + 1], G[s + 1], Xn1, 0, 0, 0);
         }
+        Xn += Xn1;
         Xt[rr] = Xn;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -269,10 +349,11 @@ __global__ __launch_bounds__(256) void gpak_potrf128_f64(double *A, long ld, dou
       }
     }
   }
+  GPAK_TS(34);
 }
 
 void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv) {
-  hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(256), 0, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
+  hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(512), 0, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
 }
 
 // Panel factorisation of one outer block column [J, J+W): all rows below it.
