@@ -8,7 +8,7 @@
 //
 // Three kernels, all 128x128 output tiles of 4x4 v_mfma_f64_16x16x4_f64 accumulators per wave:
 //   gpak_gemm_nt_f64_rs    (default)  operands streamed through registers, no LDS, no barriers
-//   gpak_gemm_nt_f64_rs32             the same with 32x32 per wave for small tile grids (panel chain)
+//   gpak_gemm_nt_f64_rs32<MI, WROWS>  the same with 32x32 or 16x32 per wave for small tile grids (panel chain)
 //   gpak_gemm_nt_f64       (GPAK_GEMM=lds, kept for comparison) K staged 16 deep through double-buffered
 //                          LDS with LDS-DMA ([k][row] images, row stride 144 doubles so that the four
 //                          k-planes a wave reads per fragment land on disjoint bank halves)
@@ -19,6 +19,7 @@
 // lane group holds consecutive matrix rows of one column.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "gpak_internal.h"
 
@@ -344,39 +345,50 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
 // (2x4) cover 64 rows x 128 columns, and a 128x128 tile is spread over two workgroups / 16 waves:
 // a quarter of the MFMA chain per wave.  Plain (ti, tj) grid, no super-tiles (nothing to reuse).
 // ---------------------------------------------------------------------------------------
+// The wave tile shrinks with the grid: MI = 2 m-tiles (32 rows) or 1 (16 rows) per wave, WROWS = 2 or 1 waves along
+// the rows, always 4 waves along the 128 columns -- 64, 32 or 16 rows x 128 columns per workgroup.  A panel solve at
+// 4096 rows is 64 workgroups of the first kind (2 waves per SIMD, 2 x 128 MFMAs = 7 us of matrix pipe on a quarter of
+// the CUs) and 256 of the last (1 wave per SIMD, 64 MFMAs = 1.8 us); the last is the default.
 #define RS32_D 8
-__global__ __launch_bounds__(512) void gpak_gemm_nt_f64_rs32(int K, double alpha, const double *A, long lda,
-                                                             const double *B, long ldb, double beta, double *C,
-                                                             long ldc, int rb0, int cb0, int lower_skip, int mt64,
-                                                             int nt, int k0_by_row) {
-  const int ti64 = blockIdx.x % mt64, tj = blockIdx.x / mt64;
-  const int ti = ti64 >> 1;  // 128-row tile index (skip rule and k-start are defined on 128-tiles)
+template <int MI, int WROWS>
+__global__ __launch_bounds__(256 * WROWS) void gpak_gemm_nt_f64_rs32(int K, double alpha, const double *A, long lda,
+                                                                      const double *B, long ldb, double beta, double *C,
+                                                                      long ldc, int rb0, int cb0, int lower_skip, int mtw,
+                                                                      int nt, int k0_by_row) {
+  constexpr int WGROWS = 16 * MI * WROWS;   // rows per workgroup
+  const int tiw = blockIdx.x % mtw, tj = blockIdx.x / mtw;
+  const int ti = tiw / (TM / WGROWS);  // 128-row tile index (skip rule and k-start are defined on 128-tiles)
   if (tj >= nt) return;
   if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
   __builtin_amdgcn_s_setprio(2);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = w & 1, wc = w >> 1;  // 2 x 4 waves of 32 x 32
+  const int wr = w % WROWS, wc = w / WROWS;  // WROWS x 4 waves
   const int l15 = lane & 15, l4 = lane >> 4;
   const int kstep0 = k0_by_row ? (rb0 + ti) * (TM / 4) : 0;
   const int n = K / 4 - kstep0;
-  const d2 *Ap = reinterpret_cast<const d2 *>(A + (size_t)ti64 * 64 + wr * 32 + 2 * l15 + (size_t)(4 * kstep0 + l4) * lda);
+  typedef typename std::conditional<MI == 2, d2, double>::type ta;
+  const ta *Ap = reinterpret_cast<const ta *>(A + (size_t)tiw * WGROWS + wr * 16 * MI + MI * l15 + (size_t)(4 * kstep0 + l4) * lda);
   const d2 *Bp = reinterpret_cast<const d2 *>(B + (size_t)tj * TN + wc * 32 + 2 * l15 + (size_t)(4 * kstep0 + l4) * ldb);
-  const size_t sa = 2 * (size_t)lda, sb = 2 * (size_t)ldb;
-  d4 acc[2][2];
+  const size_t sa = (4 / (sizeof(ta) / sizeof(double))) * (size_t)lda, sb = 2 * (size_t)ldb;
+  d4 acc[MI][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; mi++)
+  for (int mi = 0; mi < MI; mi++)
 #pragma unroll
     for (int ni = 0; ni < 2; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-  d2 ra[RS32_D], rbv[RS32_D];
+  ta ra[RS32_D];
+  d2 rbv[RS32_D];
+  auto a_of = [](const ta &v, int mi) -> double {
+    if constexpr (MI == 2) return v[mi]; else return v;
+  };
 #define RS_LOAD(slot_) \
   ra[slot_] = *Ap;     \
   rbv[slot_] = *Bp;    \
   Ap += sa;            \
   Bp += sb;
 #define RS_MFMA(slot_)                                                                                       \
-  _Pragma("unroll") for (int mi = 0; mi < 2; mi++) _Pragma("unroll") for (int ni = 0; ni < 2; ni++)          \
-      acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(rbv[slot_][ni], ra[slot_][mi], acc[mi][ni], 0, 0, 0);
+  _Pragma("unroll") for (int mi = 0; mi < MI; mi++) _Pragma("unroll") for (int ni = 0; ni < 2; ni++)         \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(rbv[slot_][ni], a_of(ra[slot_], mi), acc[mi][ni], 0, 0, 0);
 #pragma unroll
   for (int s = 0; s < RS32_D; s++) { RS_LOAD(s) }  // n >= 32 k-steps always
   int g = 0;
@@ -400,23 +412,29 @@ __global__ __launch_bounds__(512) void gpak_gemm_nt_f64_rs32(int K, double alpha
     if (s < r) { RS_MFMA(s) }
 #undef RS_LOAD
 #undef RS_MFMA
-  // in-place panel solve: the workgroup owns its 64 rows across all 128 columns, so one barrier orders
+  // in-place panel solve: the workgroup owns its rows across all 128 columns, so one barrier orders
   // every wave's operand reads before anybody's stores
   if (A == C) __syncthreads();
-  // lane holds of tile (mi, ni): C row 2*l15 + mi, C columns 2(l4 + 4r) + ni of the wave's 32 x 32
-  double *Cg = C + (size_t)ti64 * 64 + wr * 32 + 2 * l15 + ((size_t)tj * TN + wc * 32) * ldc;
+  // lane holds of tile (mi, ni): C row MI*l15 + mi, C columns 2(l4 + 4r) + ni of the wave's (16 MI) x 32
+  double *Cg = C + (size_t)tiw * WGROWS + wr * 16 * MI + MI * l15 + ((size_t)tj * TN + wc * 32) * ldc;
 #pragma unroll
   for (int ni = 0; ni < 2; ni++)
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
-      d2 *p = reinterpret_cast<d2 *>(Cg + (size_t)(2 * (l4 + 4 * r4) + ni) * ldc);
-      d2 v = {alpha * acc[0][ni][r4], alpha * acc[1][ni][r4]};
-      if (beta != 0.0) {
-        const d2 c = *p;
-        v.x = fma(alpha, acc[0][ni][r4], beta * c.x);
-        v.y = fma(alpha, acc[1][ni][r4], beta * c.y);
+      ta *p = reinterpret_cast<ta *>(Cg + (size_t)(2 * (l4 + 4 * r4) + ni) * ldc);
+      if constexpr (MI == 2) {
+        d2 v = {alpha * acc[0][ni][r4], alpha * acc[1][ni][r4]};
+        if (beta != 0.0) {
+          const d2 c = *p;
+          v.x = fma(alpha, acc[0][ni][r4], beta * c.x);
+          v.y = fma(alpha, acc[1][ni][r4], beta * c.y);
+        }
+        *p = v;
+      } else {
+        double v = alpha * acc[0][ni][r4];
+        if (beta != 0.0) v = fma(alpha, acc[0][ni][r4], beta * *p);
+        *p = v;
       }
-      *p = v;
     }
 }
 
@@ -473,8 +491,19 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
   // (the bulk trailing update keeps its own kernel whatever its size: it is never on the panel chain, and
   //  one kernel name per role keeps the rocprofv3 statistics and bench.py's event timing comparable)
   if (!use_lds && !trailing && tiles <= small_max) {
-    hipLaunchKernelGGL(gpak_gemm_nt_f64_rs32, dim3((unsigned)(2 * mt * nt)), dim3(512), 0, st, K, alpha, A, lda, B, ldb,
-                       beta, C, ldc, row_block0, col_block0, lower_skip ? 1 : 0, 2 * mt, nt, k0_by_row ? 1 : 0);
+    // rows per workgroup: the finest split measured best at every size (N = 4096: 2.38 / 2.49 / 2.69 ms per step with
+    // 16 / 32 / 64, N = 8192: 6.64 / 6.69 / 6.95, N = 32768: 181.9 / 182.0 / 182.6); GPAK_GEMM_SMALL_ROWS for A/B runs
+    static const int rows = getenv("GPAK_GEMM_SMALL_ROWS") ? atoi(getenv("GPAK_GEMM_SMALL_ROWS")) : 16;
+    const int ls = lower_skip ? 1 : 0, kr = k0_by_row ? 1 : 0;
+    if (rows == 64)
+      hipLaunchKernelGGL((gpak_gemm_nt_f64_rs32<2, 2>), dim3((unsigned)(2 * mt * nt)), dim3(512), 0, st, K, alpha, A, lda, B,
+                         ldb, beta, C, ldc, row_block0, col_block0, ls, 2 * mt, nt, kr);
+    else if (rows == 32)
+      hipLaunchKernelGGL((gpak_gemm_nt_f64_rs32<2, 1>), dim3((unsigned)(4 * mt * nt)), dim3(256), 0, st, K, alpha, A, lda, B,
+                         ldb, beta, C, ldc, row_block0, col_block0, ls, 4 * mt, nt, kr);
+    else
+      hipLaunchKernelGGL((gpak_gemm_nt_f64_rs32<1, 1>), dim3((unsigned)(8 * mt * nt)), dim3(256), 0, st, K, alpha, A, lda, B,
+                         ldb, beta, C, ldc, row_block0, col_block0, ls, 8 * mt, nt, kr);
     return;
   }
   // GPAK_GEMM=lds selects the LDS-staged kernel (kept for comparison); default: register streaming

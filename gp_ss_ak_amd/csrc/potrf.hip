@@ -56,31 +56,150 @@ __device__ __forceinline__ int gpak_tix(int rt, int ct, int i, int k) {
 //   info   : atomicMin of the first failing column (1-based)
 #ifdef GPAK_POTRF_TIMING
 __device__ long long gpak_potrf_dbg[64];
-#define GPAK_TS(i_) do { if (t == 0) gpak_potrf_dbg[i_] = (long long)__builtin_readcyclecounter(); } while (0)
+// stamps go to LDS and leave for memory when the kernel is over: a global store per stamp made the wave wait for that
+// store (behind everything else the CU had in flight) the next time its register was reused -- thousands of cycles
+// that showed up in whichever phase came next
+#define GPAK_TS(i_) do { if (t == 0) gpak_ts_lds[i_] = (long long)__builtin_readcyclecounter(); } while (0)
+#define GPAK_TSW(w_, i_) do { if (t == 64 * (w_)) gpak_ts_lds[i_] = (long long)__builtin_readcyclecounter(); } while (0)
+#define GPAK_TS_DECL __shared__ long long gpak_ts_lds[64];
+#define GPAK_TS_FLUSH() do { __syncthreads(); if (t < 64) gpak_potrf_dbg[t] = gpak_ts_lds[t]; } while (0)
 extern "C" int gpak_dev_potrf_timing(long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gpak_potrf_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
 }
 #else
 #define GPAK_TS(i_) do { } while (0)
+#define GPAK_TSW(w_, i_) do { } while (0)
+#define GPAK_TS_DECL
+#define GPAK_TS_FLUSH() do { } while (0)
 #endif
 __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv,
                                                           int col0, int *info, int zero_inv) {
-  __shared__ double T[36 * 256];
-  __shared__ double dd[8][16];
+  // one LDS array, so that "which of these does this lane write" is an integer select on an offset and not a choice
+  // between pointers (which the compiler turns into a branch tree): T = the 36 lower tiles, then dd = the diagonals
+  // of the 8 diagonal-block inverses, then one dump slot per lane
+  // (the same goes for reads: "this lane's value or a constant" written as a select on the loaded value comes back
+  // from the compiler as a branch around the load, and a taken branch costs more than the load -- so the constants
+  // live in LDS too: a 16x16 identity tile, whose off-diagonal entries double as the zero)
+  __shared__ double SM[36 * 256 + 8 * 272 + 256];
+  double *const T = SM;
+  // WI0: the inverses of the 8 diagonal blocks as full column-major 16x16 tiles (their upper halves are the exact zeros
+  // the elimination leaves there), leading dimension 17 so that both the column-per-lane write and the MFMA fragment
+  // reads are conflict-free; ID0: a 16x16 identity
+  constexpr int WI0 = 36 * 256, ID0 = WI0 + 8 * 272;
+  GPAK_TS_DECL
+  // the 28 strictly-lower 16x16 tiles of the block inverse Y = L^-1, kept TRANSPOSED (tile (i, j), i > j, holds
+  // Y[i,j]^T) so that every MFMA operand and accumulator access below is contiguous across lane&15
+  __shared__ double Y2[28 * 256];
   // this workgroup is the serial link of the panel chain and shares its CU with two trailing-update
   // waves per SIMD: let its instructions win the issue arbitration
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform for the compiler too: scalar branches, no exec-mask loops
   // wave 0 carries the serial chain (the diagonal blocks): it outranks its own helpers, which outrank everybody else
   if (w == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
   const int l15 = lane & 15, l4 = lane >> 4;
+  const int lane_ = lane, l15_ = l15, l4_ = l4;
   double *invT = inv + PB * PB;
 
   // inverse of diagonal block r, element (j,k)
   auto dinv = [&](int r, int j, int k) -> double {
-    return j > k ? T[gpak_tix(r, r, k, j)] : (j == k ? dd[r][j] : 0.0);
+    return SM[WI0 + 272 * r + 17 * k + j];
+  };
+
+  // ---- the 128x128 inverse rides along with the factorisation (it used to be a serial 19 k-cycle epilogue).
+  // Block forward substitution in right-looking form on R = I: once D_kb is factored, row block kb is finished,
+  //   Y[kb,j] = D_kb^-1 R[kb,j]  (phase A, j < kb),   and leaves the rows below,  R[i,j] -= L[i,kb] Y[kb,j]  (phase B).
+  // In the transposed storage: YT[j,kb] = RT[j,kb] D_kb^-T and RT[j,i] -= YT[j,kb] L[i,kb]^T -- both A * B^T products
+  // of column-major tiles, spread over the waves that are not on the critical path.
+  auto y2 = [&](int i, int j) -> double * { return Y2 + ((i * (i - 1) / 2 + j) << 8); };
+  auto phase_a = [&](int kb, int j) {
+    double *tile = y2(kb, j);
+    double xa[4], rb[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      xa[s4] = dinv(kb, l15, 4 * s4 + l4);
+      rb[s4] = tile[((4 * s4 + l4) << 4) + l15];
+    }
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4 += 2) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s4], rb[s4], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s4 + 1], rb[s4 + 1], acc1, 0, 0, 0);
+    }
+    acc += acc1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) tile[((l4 + 4 * r) << 4) + l15] = acc[r];
+  };
+  auto phase_b = [&](int kb, int i, int j) {
+    double *dst = y2(i, j);
+    double la[4], yb[4];
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      la[s4] = -T[gpak_tix(i, kb, l15, 4 * s4 + l4)];
+      yb[s4] = (j == kb) ? dinv(kb, 4 * s4 + l4, l15) : y2(kb, j)[((4 * s4 + l4) << 4) + l15];
+    }
+    if (j != kb) {   // (j == kb: first contribution to R[i,j], which starts at zero)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = dst[((l4 + 4 * r) << 4) + l15];
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4 += 2) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], yb[s4], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4 + 1], yb[s4 + 1], acc1, 0, 0, 0);
+    }
+    acc += acc1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) dst[((l4 + 4 * r) << 4) + l15] = acc[r];
+  };
+
+  // ---- results go out as soon as they are final (column kb of L and row kb of the inverse during step kb, by the waves
+  // that are off the critical path), 16 B per lane, 128-B runs: the epilogue used to wait for 200 KB of stores to drain
+  const int sp2 = 2 * (lane & 7), sc8 = lane >> 3;
+  auto store_l_tile = [&](int rt, int ct) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int col = sc8 + 8 * h;
+      double2 v = *reinterpret_cast<const double2 *>(&T[gpak_tix(rt, ct, sp2, col)]);
+      if (rt == ct) {                  // the diagonal tile's upper half holds leftovers: L goes out cleanly lower
+        if (sp2 < col) v.x = 0.0;
+        if (sp2 + 1 < col) v.y = 0.0;
+      }
+      *reinterpret_cast<double2 *>(A + 16 * rt + sp2 + (size_t)(16 * ct + col) * ld) = v;
+    }
+  };
+  auto store_y_tile = [&](int i, int j) {   // tile (i, j), i > j: YT(a, b) = L^-1[16 i + b][16 j + a]
+    const double *tile = y2(i, j);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int c8 = sc8 + 8 * h;
+      *reinterpret_cast<double2 *>(invT + 16 * j + sp2 + (size_t)(16 * i + c8) * PB) =
+          *reinterpret_cast<const double2 *>(&tile[(c8 << 4) + sp2]);
+      *reinterpret_cast<double2 *>(inv + 16 * i + sp2 + (size_t)(16 * j + c8) * PB) =
+          make_double2(tile[(sp2 << 4) + c8], tile[((sp2 + 1) << 4) + c8]);
+    }
+  };
+  auto store_diag_inv = [&](int i) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int c8 = sc8 + 8 * h;
+      *reinterpret_cast<double2 *>(inv + 16 * i + sp2 + (size_t)(16 * i + c8) * PB) =
+          make_double2(dinv(i, sp2, c8), dinv(i, sp2 + 1, c8));
+      *reinterpret_cast<double2 *>(invT + 16 * i + sp2 + (size_t)(16 * i + c8) * PB) =
+          make_double2(dinv(i, c8, sp2), dinv(i, c8, sp2 + 1));
+    }
+  };
+  // store jobs of step kb: L tiles (i, kb), i = kb..7; inverse tiles (kb, j), j < kb; the diagonal inverse block kb
+  auto store_jobs = [&](int kb, int first, int step) {
+    const int njobs = (8 - kb) + kb + 1;
+    for (int q = first; q < njobs; q += step) {
+      if (q < 8 - kb) store_l_tile(kb + q, kb);
+      else if (q < 8) store_y_tile(kb, q - (8 - kb));
+      else store_diag_inv(kb);
+    }
   };
 
   GPAK_TS(0);
+  if (t < 256) SM[ID0 + t] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
   // ---- load: straight into the LDS image by LDS-DMA (global_load_lds_dwordx4), no register staging, everything in
   // flight at once.  One wave instruction moves 1 KiB = columns 8h..8h+7 of one 16x16 tile: lane l brings rows
   // 2(l&7), 2(l&7)+1 of column 8h + (l>>3); 72 such pieces, 9 per wave.
@@ -111,88 +230,90 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
   }
   __syncthreads();
 
-  // diagonal block kb: factor + invert (wave 0 only), ON THE MATRIX PIPE.  The 16x16 block sits in ONE f64 accumulator
-  // (row = (lane>>4) + 4*reg, col = lane&15) in UPPER form, a second accumulator W starts as the identity.  Pivot r:
-  // row r (register r/4, lanes with lane>>4 == r%4) is scaled by d^-1/2 (v_rsq_f64 + two Newton steps, no divisions)
-  // and, masked to those lanes, IS the A and the B operand of the rank-1 update S -= u u^T (K = 4 with one live k):
-  // no element moves between lanes.  The same row operations applied to W turn the identity into L^-1 (Cholesky as
-  // Gaussian elimination on [D | I]), so the block's inverse costs one more MFMA per pivot instead of the separate
-  // substitution it needed before.  ~170 instead of ~590 cycles per pivot.
+  // diagonal block kb: factor + invert (wave 0 only), on the VECTOR pipe.  Lane c < 16 owns column c of the symmetric
+  // 16x16 block (16 registers), lanes 16..31 own the columns of an IDENTITY.  Pivot r: d = S[r][r] comes out of lane r
+  // with v_readlane, every lane forms (sqrt d, d^-1/2) itself (v_rsq_f64 + a coupled Goldschmidt iteration, no
+  // division), scales its row-r entry and applies x[i] -= u_i x[r] for i > r, u_i = U[r][i] read from lane i into an
+  // SGPR pair.  The same row operations turn the identity into L^-1 (Gaussian elimination on [D | I]): the block's
+  // inverse costs no extra instruction.  218 cycles per pivot (tools/mfma_latency.hip).
+  // Round 2 first moved this onto the matrix pipe (rank-1 updates as 16x16x4 MFMAs, no cross-lane traffic): 430
+  // cycles per pivot.  On gfx950 the f64 MFMA runs on the SAME FMA units as f64 VALU work -- a 16x16x4 f64 MFMA holds
+  // them for 64 cycles and independent v_fma_f64 of the same wave do not overlap it (probe 8 of that tool: 65 + 8 x
+  // 5.2 = 108 cycles, measured 108) -- so a K=4 MFMA that carries a K=1 update is 4x the work of the four v_fma_f64
+  // it replaces, and the square roots cannot hide behind it.
   // upd >= 0: the block first receives the update of panel column `upd`, C -= P P^T with P = tile (kb, upd) -- the
-  // "tile 0" of the trailing update, done here in registers so that the tile never goes back through LDS in between
+  // "tile 0" of the trailing update, done by this wave so that the next block does not wait for the other waves
   auto diag_block = [&](int kb, int upd) {
-    d4 S, Wm;
-    double pa[4];
-    if (upd >= 0) {
+    // opaque copies of the lane coordinates: without them every lane mask below is hoisted out of the block loop into
+    // an SGPR pair of its own, ~60 pairs that spill to VGPR lanes and come back with two v_readlane + s_nop each --
+    // more instructions than the compare they save
+    int lane = lane_, l15 = l15_, l4 = l4_;
+    asm volatile("" : "+v"(lane), "+v"(l15), "+v"(l4));
+    double *tile = &T[gpak_tix(kb, kb, 0, 0)];
+    {
+      // the tile is made fully symmetric on the way (only its lower half is trusted: the upper half is whatever the
+      // caller's upper triangle held), so the column read below is one conflict-free access per register
+      d4 acc;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) pa[s4] = T[gpak_tix(kb, upd, l15, 4 * s4 + l4)];
-    }
+      for (int r4 = 0; r4 < 4; r4++) {
+        const int k = l4 + 4 * r4;
+        acc[r4] = tile[k <= l15 ? (k << 4) + l15 : (l15 << 4) + k];
+      }
+      if (upd >= 0) {
+        double pa[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int row = l4 + 4 * q;
-      S[q] = (l15 >= row) ? T[gpak_tix(kb, kb, l15, row)] : 0.0;   // S[row][col] = A[col][row]: the stored lower part
-      Wm[q] = (l15 == row) ? 1.0 : 0.0;
-    }
-    if (upd >= 0) {
+        for (int s4 = 0; s4 < 4; s4++) pa[s4] = T[gpak_tix(kb, upd, l15, 4 * s4 + l4)];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) S = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[s4], pa[s4], S, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[s4], -pa[s4], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) tile[((l4 + 4 * r4) << 4) + l15] = acc[r4];
     }
-    int bad = 16;   // first non-positive pivot of this block
-    // software pipeline: (g, ri) = (sqrt, 1/sqrt) of pivot r are computed on the vector pipe while the matrix pipe
-    // still applies pivot r-1.  Uf / Wf collect the finished rows (the accumulators keep the unscaled ones: the A
-    // operand of an update is zero on its own row, so finished rows are never touched again)
-    d4 Uf = (d4){0.0, 0.0, 0.0, 0.0}, Wf = (d4){0.0, 0.0, 0.0, 0.0};
-    double g, ri;
-    auto root = [&](double dv, int r) {   // coupled (Goldschmidt) iteration: g -> sqrt(d), h -> 0.5 / sqrt(d)
+    if (kb == 3) GPAK_TS(50);
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      x[i] = SM[(l4 == 0 ? gpak_tix(kb, kb, 0, 0) : ID0) + (i << 4) + l15];   // S[l15][i] = S[i][l15], or the identity
+    }
+    int bad = 16;   // first non-positive pivot of this block (branch-free: the 16 pivots stay one basic block)
+    if (kb == 3) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])); GPAK_TS(51); }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      if (kb == 3 && r == 8) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])); GPAK_TS(52); }
+      double dv = gpak_rdlane(x[r], r);
       const bool ok = dv > 0.0;
-      bad = (!ok && bad == 16) ? r : bad;
+      bad = min(bad, ok ? 16 : r);
       dv = ok ? dv : 1.0;
+      // coupled (Goldschmidt) iteration: g -> sqrt(d), h -> 0.5 / sqrt(d)
       const double y = __builtin_amdgcn_rsq(dv);
       double gg = dv * y, h = 0.5 * y;
       double e = fma(-h, gg, 0.5);
       gg = fma(gg, e, gg);
       h = fma(h, e, h);
       e = fma(-h, gg, 0.5);
-      g = fma(gg, e, gg);
+      const double g = fma(gg, e, gg);
       h = fma(h, e, h);
-      ri = h + h;
-    };
-    root(gpak_rdlane(S[0], 0), 0);
+      const double ri = h + h;
+      double xr = x[r] * ri;
+      xr = (lane == r) ? g : xr;
+      x[r] = xr;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int q = r >> 2, k4 = r & 3;
-      const bool myrow = l4 == k4;
-      double mu = S[q] * ri;
-      mu = (l15 == r) ? g : mu;
-      mu = (myrow && l15 >= r) ? mu : 0.0;              // U[r][c], c >= r, on the lanes of row r; 0 elsewhere
-      const double ma = (l15 == r) ? 0.0 : mu;          // A operand: zero on row r itself
-      const double mw = myrow ? Wm[q] * ri : 0.0;       // (L^-1)[r][c]
-      Uf[q] = myrow ? mu : Uf[q];
-      Wf[q] = myrow ? mw : Wf[q];
-      double sn = 0.0;
-      if (r < 15) sn = gpak_rdlane(S[(r + 1) >> 2], (r + 1) + 16 * ((r + 1) & 3));   // S[r+1][r+1] before this update
-      __builtin_amdgcn_sched_barrier(0);
-      if (r < 15) {
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-ma, mu, S, 0, 0, 0);     // S[i][c] -= U[r][i] U[r][c], i > r
-        Wm = __builtin_amdgcn_mfma_f64_16x16x4f64(-ma, mw, Wm, 0, 0, 0);   // W[i][c] -= U[r][i] W[r][c], i > r
+      for (int i = r + 1; i < 16; i++) {
+        const double ui = gpak_rdlane(xr, i);   // U[r][i] = L[i][r]
+        x[i] = fma(-ui, xr, x[i]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (r < 15) {
-        const double un = gpak_rdlane(mu, (r + 1) + 16 * k4);               // U[r][r+1]
-        root(fma(-un, un, sn), r + 1);                                      // the next pivot, beside the MFMAs
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
-    S = Uf; Wm = Wf;
+    if (kb == 3) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])); GPAK_TS(53); }
     if (bad < 16 && lane == 0) atomicMin(info, col0 + 16 * kb + bad + 1);
+    // lane c < 16: x[r] = L[c][r] for r <= c (beyond that: leftovers, which land in the tile's unused upper half);
+    // lanes 16 + c: x[r] = (L^-1)[r][c], exact zeros for r < c.  One store per register, no per-register lane masks
+    if (l4 < 2) {
+      double *dst = SM + (l4 == 0 ? gpak_tix(kb, kb, 0, 0) + l15 : WI0 + 272 * kb + 17 * l15);
+      const int step = l4 == 0 ? 16 : 1;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int k = l4 + 4 * q;                       // S holds U[k][l15] = L[l15][k]; Wm holds (L^-1)[k][l15]
-      if (l15 >= k) T[gpak_tix(kb, kb, l15, k)] = S[q];            // L, lower part
-      // the inverse is parked (transposed) in the strictly-upper part of the tile, its diagonal in dd[]
-      if (k > l15) T[gpak_tix(kb, kb, l15, k)] = Wm[q];
-      if (k == l15) dd[kb][k] = Wm[q];
+      for (int r = 0; r < 16; r++) dst[r * step] = x[r];
     }
+    if (kb == 3) GPAK_TS(54);
   };
 
   GPAK_TS(1);
@@ -213,6 +334,7 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
           xb[s] = dinv(kb, l15, 4 * s + l4);   // B[k][j] = inv(D)[j][k]
           pa[s] = T[gpak_tix(rt, kb, l15, 4 * s + l4)];
         }
+        if (kb == 3) { GPAK_TSW(1, 45); asm volatile("" : "+v"(xb[0]), "+v"(pa[0]), "+v"(xb[3]), "+v"(pa[3])); GPAK_TSW(1, 46); }
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};   // two chains of two (see the inverse below)
 #pragma unroll
         // operand roles swapped: the accumulator holds P^T (row of P = lane&15), so its four registers go back to
@@ -222,134 +344,95 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
           acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[s + 1], pa[s + 1], acc1, 0, 0, 0);
         }
         acc += acc1;
+        if (kb == 3) { asm volatile("" : "+v"(acc)); GPAK_TSW(1, 47); }
 #pragma unroll
         for (int r = 0; r < 4; r++) T[gpak_tix(rt, kb, l15, l4 + 4 * r)] = acc[r];
+        if (kb == 3) { asm volatile("s_waitcnt lgkmcnt(0)"); GPAK_TSW(1, 48); }
+      } else if (7 - w < kb) {
+        phase_a(kb, 7 - w);   // the top waves have no panel tile: row block kb of the inverse, columns j < kb
       }
     }
     __syncthreads();
+    if (kb == 3) GPAK_TSW(1, 49);
     GPAK_TS(3 + 4 * kb);
     // ---- trailing update of the lower tiles C(ti,tj) -= P_ti P_tj^T.  Tile 0 is the next
     // diagonal tile: wave 0 updates it and goes straight on to factor it; waves 1..3 share the
     // other tiles, four independent tiles in flight at a time.
     const int ntile = nt * (nt + 1) / 2;
-    auto trailing_tiles = [&](int q0, int qstep) {
-      for (int qb = q0; qb < ntile; qb += 4 * qstep) {
-        d4 acc[4];
-        int rti[4], rtj[4];
-        bool ok[4];
+    // up to four tiles per round, every LDS read requested before the first MFMA; NU is a compile-time count so that
+    // a short last round issues no MFMA for tiles that do not exist (an f64 16x16x4 MFMA holds the SIMD's FMA units
+    // for 64 cycles whether its result is wanted or not)
+    auto trailing_round = [&](int qb, int qstep, auto nu_tag) {
+      constexpr int NU = decltype(nu_tag)::value;
+      d4 acc[NU];
+      double pa[NU][4], pb[NU][4];
+      int rti[NU], rtj[NU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int q = qb + u * qstep;
-          ok[u] = q < ntile;
-          int ti = 0, rem = ok[u] ? q : 0;
-          while (rem > ti) { rem -= ti + 1; ti++; }  // q -> (ti, tj=rem), tj <= ti
-          rti[u] = kb + 1 + ti; rtj[u] = kb + 1 + rem;
-          if (ok[u]) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[u][r] = T[gpak_tix(rti[u], rtj[u], l15, l4 + 4 * r)];   // C^T: conflict-free
-          }
-        }
+      for (int u = 0; u < NU; u++) {
+        int ti = 0, rem = qb + u * qstep;
+        while (rem > ti) { rem -= ti + 1; ti++; }  // q -> (ti, tj=rem), tj <= ti
+        rti[u] = kb + 1 + ti; rtj[u] = kb + 1 + rem;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (ok[u]) {
-              const double pa = -T[gpak_tix(rti[u], kb, l15, 4 * s + l4)];
-              const double pb = T[gpak_tix(rtj[u], kb, l15, 4 * s + l4)];
-              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb, pa, acc[u], 0, 0, 0);
-            }
+          pa[u][s] = -T[gpak_tix(rti[u], kb, l15, 4 * s + l4)];
+          pb[u][s] = T[gpak_tix(rtj[u], kb, l15, 4 * s + l4)];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (ok[u]) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) T[gpak_tix(rti[u], rtj[u], l15, l4 + 4 * r)] = acc[u][r];
-          }
+        for (int r = 0; r < 4; r++) acc[u][r] = T[gpak_tix(rti[u], rtj[u], l15, l4 + 4 * r)];   // C^T: conflict-free
       }
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int u = 0; u < NU; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[u][s], pa[u][s], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[gpak_tix(rti[u], rtj[u], l15, l4 + 4 * r)] = acc[u][r];
+      }
+    };
+    auto trailing_tiles = [&](int q0, int qstep) {
+      int qb = q0;
+      for (; qb + 3 * qstep < ntile; qb += 4 * qstep) trailing_round(qb, qstep, std::integral_constant<int, 4>());
+      const int left = qb < ntile ? (ntile - qb + qstep - 1) / qstep : 0;
+      if (left == 3) trailing_round(qb, qstep, std::integral_constant<int, 3>());
+      else if (left == 2) trailing_round(qb, qstep, std::integral_constant<int, 2>());
+      else if (left == 1) trailing_round(qb, qstep, std::integral_constant<int, 1>());
     };
     if (w == 0) {
       GPAK_TS(4 + 4 * kb);
       diag_block(kb + 1, kb);         // tile 0 = (kb+1, kb+1): update and factor in registers
       GPAK_TS(5 + 4 * kb);
+#ifdef GPAK_NO_HELPERS
+    } else if (w >= 1) {
+#endif
+    } else if (w == 4) {
+      // wave 4 shares its SIMD (and that SIMD's MFMA pipe) with wave 0: it gets the work that needs no MFMA
+      if (kb == 0) GPAK_TSW(4, 42);
+      store_jobs(kb, 0, 1);           // column kb of L and row kb of the inverse are final
+      if (kb == 0) GPAK_TSW(4, 43);
     } else {
-      trailing_tiles(w, 7);           // tiles 1.. in steps of 7 waves
+      const int h = w < 4 ? w - 1 : w - 2;   // 0..5
+      if (kb == 0) GPAK_TSW(1, 44);
+      trailing_tiles(h + 1, 6);       // tiles 1.. in steps of 6 waves
+      if (kb == 0) GPAK_TSW(1, 40);
+      // phase B of the inverse: (7 - kb)(kb + 1) tile products, dealt round-robin to the same six waves
+      const int nprod = (7 - kb) * (kb + 1);
+      for (int q = h; q < nprod; q += 6) phase_b(kb, kb + 1 + q / (kb + 1), q % (kb + 1));
+      if (kb == 0) GPAK_TSW(1, 41);
     }
     __syncthreads();
     GPAK_TS(6 + 4 * kb);
   }
   GPAK_TS(32);
 
-  // L out (upper part of the block zeroed so the stored matrix is cleanly lower)
-#pragma unroll 8
-  for (int it = 0; it < 16; it++) {
-    const int e = t + 512 * it, r = (e & 63) * 2, c = e >> 6;
-    double2 v = make_double2(0.0, 0.0);
-    if ((r >> 4) >= (c >> 4)) {
-      v = *reinterpret_cast<const double2 *>(&T[gpak_tix(r >> 4, c >> 4, r & 15, c & 15)]);
-      if (r < c) v.x = 0.0;          // the diagonal tile's upper half holds the parked inverse
-      if (r + 1 < c) v.y = 0.0;
-    }
-    *reinterpret_cast<double2 *>(A + r + (size_t)c * ld) = v;
-  }
-
   GPAK_TS(33);
-  // 128x128 inverse, block column c per wave pass: X_cc = inv(D_c),
-  // X_rc = -inv(D_r) * sum_{k=c..r-1} L_rk X_kc
-  {
-    // eight waves, one block column each; waves w and w+4 share a SIMD (and its matrix pipe): pair the long columns
-    // with the short ones (0,7) (1,6) (2,5) (3,4)
-    const int c = w < 4 ? w : 11 - w;
-    d4 Xt[8];
-#pragma unroll
-    for (int s = 0; s < 4; s++) Xt[0][s] = dinv(c, l4 + 4 * s, l15);
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const int row = 16 * c + l4 + 4 * s, col = 16 * c + l15;
-      inv[row + col * PB] = Xt[0][s];
-      invT[col + row * PB] = Xt[0][s];
-    }
-#pragma unroll
-    for (int rr = 1; rr < 8; rr++) {
-      if (c + rr <= 7) {
-        const int r = c + rr;
-        // every LDS operand of this block row is requested before the first MFMA (the chain is 4 rr + 4 dependent
-        // MFMAs: with a read in front of each one the LDS latency, not the matrix pipe, set the pace)
-        double la[7][4], da[4];
-#pragma unroll
-        for (int m = 0; m < rr; m++)
-#pragma unroll
-          for (int s = 0; s < 4; s++) la[m][s] = T[gpak_tix(r, c + m, l15, 4 * s + l4)];
-#pragma unroll
-        for (int s = 0; s < 4; s++) da[s] = -dinv(r, l15, 4 * s + l4);
-        // two interleaved accumulator chains: a DEPENDENT f64 MFMA issues every ~130 cycles, an independent one
-        // every 64
-        d4 G = (d4){0.0, 0.0, 0.0, 0.0}, G1 = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int m = 0; m < rr; m++)
-#pragma unroll
-          for (int s = 0; s < 4; s += 2) {
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(la[m][s], Xt[m][s], G, 0, 0, 0);
-            G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[m][s + 1], Xt[m][s + 1], G1, 0, 0, 0);
-          }
-        G += G1;
-        d4 Xn = (d4){0.0, 0.0, 0.0, 0.0}, Xn1 = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; s += 2) {
-          Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(da[s], G[s], Xn, 0, 0, 0);
-          Xn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[s + 1], G[s + 1], Xn1, 0, 0, 0);
-        }
-        Xn += Xn1;
-        Xt[rr] = Xn;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int row = 16 * r + l4 + 4 * s, col = 16 * c + l15;
-          inv[row + col * PB] = Xn[s];
-          invT[col + row * PB] = Xn[s];
-        }
-      }
-    }
-  }
+  // what is left: the last row block of the inverse, then column 7 of L and row 7 of the inverse
+  if (w >= 1) phase_a(7, w - 1);
+  __syncthreads();
+  store_jobs(7, w, 8);
   GPAK_TS(34);
+  GPAK_TS_FLUSH();
 }
 
 void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv) {
