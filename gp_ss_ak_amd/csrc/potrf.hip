@@ -199,36 +199,44 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
   };
 
   GPAK_TS(0);
-  if (t < 256) SM[ID0 + t] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
   // ---- load: straight into the LDS image by LDS-DMA (global_load_lds_dwordx4), no register staging, everything in
   // flight at once.  One wave instruction moves 1 KiB = columns 8h..8h+7 of one 16x16 tile: lane l brings rows
-  // 2(l&7), 2(l&7)+1 of column 8h + (l>>3); 72 such pieces, 9 per wave.
+  // 2(l&7), 2(l&7)+1 of column 8h + (l>>3); 72 such pieces.  Wave 0 brings only the two pieces of the first diagonal
+  // tile and starts factoring it the moment they land; the other 70 pieces (10 per wave) arrive behind that.
   {
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
-    const int wu = __builtin_amdgcn_readfirstlane(w);
     const int li = 2 * (lane & 7), lk = lane >> 3;
-#pragma unroll
-    for (int p = 0; p < 9; p++) {
-      const int c = wu + 8 * p, slot = c >> 1, half = c & 1;
+    auto piece = [&](int c) {
+      const int slot = c >> 1, half = c & 1;
       int rt = 0, rem = slot;
       while (rem > rt) { rem -= rt + 1; rt++; }   // slot -> (rt, ct = rem), scalar
       const double *src = A + (16 * rt + li) + (size_t)(16 * rem + 8 * half + lk) * ld;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&T[(slot << 8) + (half << 7)], 16, 0, 0);
+    };
+    if (w == 0) {
+      piece(0);
+      piece(1);
+#pragma unroll
+      for (int q = 0; q < 4; q++) SM[ID0 + lane + 64 * q] = ((lane + 64 * q) >> 4) == (lane & 15) ? 1.0 : 0.0;
+    } else {
+#pragma unroll
+      for (int p = 0; p < 10; p++) piece(2 + (w - 1) + 7 * p);
     }
   }
-  if (zero_inv) {
+  if (zero_inv && w >= 1) {
     // the caller's inverse buffers are not known to be zero outside the triangles written at the end (the context's
     // own are zeroed once in gpak_set_train)
     const double2 z = make_double2(0.0, 0.0);
-#pragma unroll 8
-    for (int it = 0; it < 16; it++) {
-      const int e = t + 512 * it, r = (e & 63) * 2, c = e >> 6;
-      if ((r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;        // inv^T is upper
-      else if ((r >> 4) < (c >> 4)) *reinterpret_cast<double2 *>(inv + r + c * PB) = z;   // inv is lower
+#pragma unroll 4
+    for (int it = 0; it < 19; it++) {
+      const int e = (t - 64) + 448 * it, r = (e & 63) * 2, c = e >> 6;
+      if (e < 8192) {
+        if ((r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;        // inv^T is upper
+        else if ((r >> 4) < (c >> 4)) *reinterpret_cast<double2 *>(inv + r + c * PB) = z;   // inv is lower
+      }
     }
   }
-  __syncthreads();
 
   // diagonal block kb: factor + invert (wave 0 only), on the VECTOR pipe.  Lane c < 16 owns column c of the symmetric
   // 16x16 block (16 registers), lanes 16..31 own the columns of an IDENTITY.  Pivot r: d = S[r][r] comes out of lane r
@@ -317,7 +325,10 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
   };
 
   GPAK_TS(1);
-  if (w == 0) diag_block(0, -1);
+  if (w == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own two pieces: no barrier before the first block
+    diag_block(0, -1);
+  }
   GPAK_TS(2);
   __syncthreads();
 
