@@ -266,10 +266,11 @@ void gpak_launch_rowsumsq_f32(hipStream_t st, const float *V, long ldv, int rows
 
 // ---- potrf.hip --------------------------------------------------------------------------
 // Factor the 128x128 block at A (ld) in place (lower), write its inverse to inv (128x128, ld 128).
-void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv);
+void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv,
+                          bool co = false);
 int gpak_potrf_blocked(gpak_ctx *ctx);
 void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                       bool zero_inv);
+                       bool zero_inv, bool co = false);
 
 // ---- solve.hip --------------------------------------------------------------------------
 // x := L^-1 x ; x := L^-T x  (x has Np entries) using the inverted diagonal blocks.

@@ -61,7 +61,7 @@ __device__ long long gpak_potrf_dbg[64];
 // that showed up in whichever phase came next
 #define GPAK_TS(i_) do { if (t == 0) gpak_ts_lds[i_] = (long long)__builtin_readcyclecounter(); } while (0)
 #define GPAK_TSW(w_, i_) do { if (t == 64 * (w_)) gpak_ts_lds[i_] = (long long)__builtin_readcyclecounter(); } while (0)
-#define GPAK_TS_DECL __shared__ long long gpak_ts_lds[64];
+#define GPAK_TS_DECL long long *const gpak_ts_lds = reinterpret_cast<long long *>(SM + GPAK_POTRF_SM_DOUBLES + 28 * 256);
 #define GPAK_TS_FLUSH() do { __syncthreads(); if (t < 64) gpak_potrf_dbg[t] = gpak_ts_lds[t]; } while (0)
 extern "C" int gpak_dev_potrf_timing(long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gpak_potrf_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
@@ -72,15 +72,26 @@ extern "C" int gpak_dev_potrf_timing(long long *out) {
 #define GPAK_TS_DECL
 #define GPAK_TS_FLUSH() do { } while (0)
 #endif
-__global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv,
-                                                          int col0, int *info, int zero_inv) {
+#define GPAK_POTRF_SM_DOUBLES (36 * 256 + 8 * 272 + 256)
+#define GPAK_POTRF_LDS_BYTES ((GPAK_POTRF_SM_DOUBLES + 28 * 256 + 64) * 8)
+// NW = 8 waves: the fast one (26.5 us).  Its waves need 141 VGPRs, two per SIMD: beside the bulk trailing update (two
+// 210-VGPR waves per SIMD on every CU) it cannot start until a CU has lost one of its two bulk workgroups AND the
+// dispatcher gives the hole to this kernel -- observed to take up to the whole bulk update (7 ms, tools/chain_trace.sh
+// 32768).  NW = 4 waves capped at 80 VGPRs, one per SIMD, fits into the 80 registers two bulk waves leave free: it is
+// slower alone but starts at once, and is what the factorisation launches while bulk updates are large.
+template <int NW>
+__device__ __forceinline__ void gpak_potrf128_body(double *A, long ld, double *__restrict__ inv, int col0, int *info,
+                                                    int zero_inv) {
   // one LDS array, so that "which of these does this lane write" is an integer select on an offset and not a choice
   // between pointers (which the compiler turns into a branch tree): T = the 36 lower tiles, then dd = the diagonals
   // of the 8 diagonal-block inverses, then one dump slot per lane
   // (the same goes for reads: "this lane's value or a constant" written as a select on the loaded value comes back
   // from the compiler as a branch around the load, and a taken branch costs more than the load -- so the constants
   // live in LDS too: a 16x16 identity tile, whose off-diagonal entries double as the zero)
-  __shared__ double SM[36 * 256 + 8 * 272 + 256];
+  // (dynamic LDS: with a static 132 KiB the compiler concludes that only one workgroup fits on a CU anyway and
+  // ignores the register budget the 4-wave build asks for)
+  extern __shared__ double gpak_potrf_lds[];
+  double *const SM = gpak_potrf_lds;
   double *const T = SM;
   // WI0: the inverses of the 8 diagonal blocks as full column-major 16x16 tiles (their upper halves are the exact zeros
   // the elimination leaves there), leading dimension 17 so that both the column-per-lane write and the MFMA fragment
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
   GPAK_TS_DECL
   // the 28 strictly-lower 16x16 tiles of the block inverse Y = L^-1, kept TRANSPOSED (tile (i, j), i > j, holds
   // Y[i,j]^T) so that every MFMA operand and accumulator access below is contiguous across lane&15
-  __shared__ double Y2[28 * 256];
+  double *const Y2 = SM + GPAK_POTRF_SM_DOUBLES;
   // this workgroup is the serial link of the panel chain and shares its CU with two trailing-update
   // waves per SIMD: let its instructions win the issue arbitration
   const int t = threadIdx.x, lane = t & 63;
@@ -221,7 +232,10 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
       for (int q = 0; q < 4; q++) SM[ID0 + lane + 64 * q] = ((lane + 64 * q) >> 4) == (lane & 15) ? 1.0 : 0.0;
     } else {
 #pragma unroll
-      for (int p = 0; p < 10; p++) piece(2 + (w - 1) + 7 * p);
+      for (int p = 0; p < (70 + NW - 2) / (NW - 1); p++) {
+        const int c = 2 + (w - 1) + (NW - 1) * p;
+        if (c < 72) piece(c);
+      }
     }
   }
   if (zero_inv && w >= 1) {
@@ -229,8 +243,8 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
     // own are zeroed once in gpak_set_train)
     const double2 z = make_double2(0.0, 0.0);
 #pragma unroll 4
-    for (int it = 0; it < 19; it++) {
-      const int e = (t - 64) + 448 * it, r = (e & 63) * 2, c = e >> 6;
+    for (int it = 0; it < (8192 + 64 * (NW - 1) - 1) / (64 * (NW - 1)); it++) {
+      const int e = (t - 64) + 64 * (NW - 1) * it, r = (e & 63) * 2, c = e >> 6;
       if (e < 8192) {
         if ((r >> 4) > (c >> 4)) *reinterpret_cast<double2 *>(invT + r + c * PB) = z;        // inv^T is upper
         else if ((r >> 4) < (c >> 4)) *reinterpret_cast<double2 *>(inv + r + c * PB) = z;   // inv is lower
@@ -336,17 +350,18 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
     const int nt = 7 - kb;  // 16-row tiles below the diagonal block
     // ---- panel tiles: P := P * inv(D)^T  (a tile depends only on itself: no barrier inside); one tile per wave,
     // all operands requested before the first MFMA
-    {
-      const int rt = kb + 1 + w;
-      if (rt < 8) {
+    // seven 16x16x16 products: the 7 - kb panel tiles, then the kb phase-A products (row block kb of the inverse,
+    // columns j < kb); one per wave with 8 waves, two rounds with 4
+    for (int q = w; q < 7; q += NW) {
+      if (q < 7 - kb) {
+        const int rt = kb + 1 + q;
         double pa[4], xb[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           xb[s] = dinv(kb, l15, 4 * s + l4);   // B[k][j] = inv(D)[j][k]
           pa[s] = T[gpak_tix(rt, kb, l15, 4 * s + l4)];
         }
-        if (kb == 3) { GPAK_TSW(1, 45); asm volatile("" : "+v"(xb[0]), "+v"(pa[0]), "+v"(xb[3]), "+v"(pa[3])); GPAK_TSW(1, 46); }
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};   // two chains of two (see the inverse below)
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};   // two chains of two
 #pragma unroll
         // operand roles swapped: the accumulator holds P^T (row of P = lane&15), so its four registers go back to
         // LDS as 16 consecutive doubles per lane group instead of a 128-B stride (8-way bank conflict)
@@ -355,16 +370,13 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
           acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[s + 1], pa[s + 1], acc1, 0, 0, 0);
         }
         acc += acc1;
-        if (kb == 3) { asm volatile("" : "+v"(acc)); GPAK_TSW(1, 47); }
 #pragma unroll
         for (int r = 0; r < 4; r++) T[gpak_tix(rt, kb, l15, l4 + 4 * r)] = acc[r];
-        if (kb == 3) { asm volatile("s_waitcnt lgkmcnt(0)"); GPAK_TSW(1, 48); }
-      } else if (7 - w < kb) {
-        phase_a(kb, 7 - w);   // the top waves have no panel tile: row block kb of the inverse, columns j < kb
+      } else {
+        phase_a(kb, q - (7 - kb));
       }
     }
     __syncthreads();
-    if (kb == 3) GPAK_TSW(1, 49);
     GPAK_TS(3 + 4 * kb);
     // ---- trailing update of the lower tiles C(ti,tj) -= P_ti P_tj^T.  Tile 0 is the next
     // diagonal tile: wave 0 updates it and goes straight on to factor it; waves 1..3 share the
@@ -403,34 +415,34 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
       }
     };
     auto trailing_tiles = [&](int q0, int qstep) {
+      constexpr int NUMAX = NW == 8 ? 4 : 2;   // tiles in flight per wave (register budget of the 4-wave build)
       int qb = q0;
-      for (; qb + 3 * qstep < ntile; qb += 4 * qstep) trailing_round(qb, qstep, std::integral_constant<int, 4>());
+      for (; qb + (NUMAX - 1) * qstep < ntile; qb += NUMAX * qstep) trailing_round(qb, qstep, std::integral_constant<int, NUMAX>());
       const int left = qb < ntile ? (ntile - qb + qstep - 1) / qstep : 0;
-      if (left == 3) trailing_round(qb, qstep, std::integral_constant<int, 3>());
-      else if (left == 2) trailing_round(qb, qstep, std::integral_constant<int, 2>());
-      else if (left == 1) trailing_round(qb, qstep, std::integral_constant<int, 1>());
+      if constexpr (NUMAX == 4) {
+        if (left == 3) trailing_round(qb, qstep, std::integral_constant<int, 3>());
+        else if (left == 2) trailing_round(qb, qstep, std::integral_constant<int, 2>());
+      }
+      if (left == 1) trailing_round(qb, qstep, std::integral_constant<int, 1>());
     };
     if (w == 0) {
       GPAK_TS(4 + 4 * kb);
       diag_block(kb + 1, kb);         // tile 0 = (kb+1, kb+1): update and factor in registers
       GPAK_TS(5 + 4 * kb);
-#ifdef GPAK_NO_HELPERS
-    } else if (w >= 1) {
-#endif
-    } else if (w == 4) {
-      // wave 4 shares its SIMD (and that SIMD's MFMA pipe) with wave 0: it gets the work that needs no MFMA
-      if (kb == 0) GPAK_TSW(4, 42);
+    } else if (NW == 8 && w == 4) {
+      // wave 4 shares its SIMD (and that SIMD's FMA units) with wave 0: it gets the work that needs no MFMA
       store_jobs(kb, 0, 1);           // column kb of L and row kb of the inverse are final
-      if (kb == 0) GPAK_TSW(4, 43);
     } else {
-      const int h = w < 4 ? w - 1 : w - 2;   // 0..5
+      constexpr int NH = NW == 8 ? 6 : 3;   // MFMA helper waves, on the SIMDs wave 0 is not on
+      const int h = NW == 8 ? (w < 4 ? w - 1 : w - 2) : w - 1;
       if (kb == 0) GPAK_TSW(1, 44);
-      trailing_tiles(h + 1, 6);       // tiles 1.. in steps of 6 waves
+      trailing_tiles(h + 1, NH);      // tiles 1.. in steps of NH waves
       if (kb == 0) GPAK_TSW(1, 40);
-      // phase B of the inverse: (7 - kb)(kb + 1) tile products, dealt round-robin to the same six waves
+      // phase B of the inverse: (7 - kb)(kb + 1) tile products, dealt round-robin to the same waves
       const int nprod = (7 - kb) * (kb + 1);
-      for (int q = h; q < nprod; q += 6) phase_b(kb, kb + 1 + q / (kb + 1), q % (kb + 1));
+      for (int q = h; q < nprod; q += NH) phase_b(kb, kb + 1 + q / (kb + 1), q % (kb + 1));
       if (kb == 0) GPAK_TSW(1, 41);
+      if (NW != 8) store_jobs(kb, h, NH);
     }
     __syncthreads();
     GPAK_TS(6 + 4 * kb);
@@ -439,15 +451,32 @@ __global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, dou
 
   GPAK_TS(33);
   // what is left: the last row block of the inverse, then column 7 of L and row 7 of the inverse
-  if (w >= 1) phase_a(7, w - 1);
+  for (int j = w; j < 7; j += NW) phase_a(7, j);
   __syncthreads();
-  store_jobs(7, w, 8);
+  store_jobs(7, w, NW);
   GPAK_TS(34);
   GPAK_TS_FLUSH();
 }
 
-void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv) {
-  hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(512), 0, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
+__global__ __launch_bounds__(512) void gpak_potrf128_f64(double *A, long ld, double *__restrict__ inv, int col0, int *info,
+                                                          int zero_inv) {
+  gpak_potrf128_body<8>(A, ld, inv, col0, info, zero_inv);
+}
+__global__ __launch_bounds__(256, 6)
+void gpak_potrf128_co_f64(double *A, long ld, double *__restrict__ inv, int col0, int *info, int zero_inv) {
+  gpak_potrf128_body<4>(A, ld, inv, col0, info, zero_inv);
+}
+
+void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv, bool co) {
+  static const bool attr_ok = [] {   // 132 KiB of dynamic LDS needs the opt-in, once per kernel
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(gpak_potrf128_f64), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GPAK_POTRF_LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void *>(gpak_potrf128_co_f64),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GPAK_POTRF_LDS_BYTES) == hipSuccess;
+  }();
+  (void)attr_ok;
+  if (co) hipLaunchKernelGGL(gpak_potrf128_co_f64, dim3(1), dim3(256), GPAK_POTRF_LDS_BYTES, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
+  else hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(512), GPAK_POTRF_LDS_BYTES, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
 }
 
 // Panel factorisation of one outer block column [J, J+W): all rows below it.
@@ -455,10 +484,10 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
 // rank that stores just this block column passes a virtual base (see dev_api.hip).
 // One level: 128-column steps, each followed by the K=128 update of the columns [j+128, J+W).
 static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                             bool zero_inv) {
+                             bool zero_inv, bool co) {
   for (int j = J; j < J + W; j += PB) {
     double *inv = inv_base + (size_t)(j / PB) * 2 * PB * PB;
-    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info, zero_inv);
+    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info, zero_inv, co);
     const int mt = (Np - j - PB) / PB;
     if (mt > 0) {
       double *P = M + (j + PB) + (size_t)j * ld;
@@ -474,10 +503,10 @@ static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, 
 // of the rest of the panel in between (three-level blocking: 128 / MID / W).
 #define GPAK_PANEL_MID 512
 void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                       bool zero_inv) {
+                       bool zero_inv, bool co) {
   for (int j = J; j < J + W; j += GPAK_PANEL_MID) {
     const int w = (J + W - j) < GPAK_PANEL_MID ? (J + W - j) : GPAK_PANEL_MID;
-    factor_panel_128(st, M, ld, Np, j, w, inv_base, info, zero_inv);
+    factor_panel_128(st, M, ld, Np, j, w, inv_base, info, zero_inv, co);
     const int c0 = j + w, nct = (J + W - c0) / PB, mt = (Np - c0) / PB;
     if (nct > 0 && mt > 0) {
       const double *P = M + c0 + (size_t)j * ld;
@@ -485,9 +514,9 @@ void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W,
     }
   }
 }
-static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W) {
+static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W, bool co) {
   // ctx->dInv is zeroed once in gpak_set_train and only ever written inside its triangles
-  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false);
+  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false, co);
 }
 
 // Chain-bound tail: the same panel factorisation (W <= 512), but the update of the NEXT block column [J1, J2) is
@@ -504,7 +533,7 @@ static int factor_panel_tail(gpak_ctx *ctx, hipStream_t sp, hipStream_t sx, int 
   int k = 0;
   for (int j = J; j < J + W; j += PB, k++) {
     double *inv = ctx->dInv + (size_t)(j / PB) * 2 * PB * PB;
-    gpak_launch_potrf128(sp, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo, false);
+    gpak_launch_potrf128(sp, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo, false, false);
     const int mt = (Np - j - PB) / PB;
     if (mt <= 0) continue;
     double *P = M + (j + PB) + (size_t)j * ld;
@@ -593,6 +622,9 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   // N=32768 -- the four K=128 products re-read and re-write the column four times and the chain gains nothing
   // measurable; off unless GPAK_SUB_NEXT=1 (kept: the multi-GPU schedule is built the same way and tests compare)
   static const bool sub_next = getenv("GPAK_SUB_NEXT") && atoi(getenv("GPAK_SUB_NEXT")) != 0;
+  // GPAK_POTRF_CO: 0 = always the 8-wave potrf128, 1 (default) = the co-resident 4-wave one beside unmasked bulk
+  // updates, 2 = always the 4-wave one
+  static const int co_mode = getenv("GPAK_POTRF_CO") ? atoi(getenv("GPAK_POTRF_CO")) : 1;
   bool next_col_done = false;   // the next block column already has this panel's update (applied per sub-panel)
   for (int b = 0; b < nJ; b++) {
     const int J = Js[b], W = Js[b + 1] - J;
@@ -603,7 +635,10 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
       if (rc) return rc;
       next_col_done = true;
     } else {
-      factor_panel(ctx, sp, J, W);
+      // panel b is factored while the bulk update of panel b-1 (rows >= J + W) runs: on the unmasked stream that
+      // update holds two 210-VGPR waves on every SIMD of the chip, and only the 4-wave, 80-VGPR potrf128 fits beside it
+      const bool beside_bulk = ctx->lookahead && b > 0 && !(ctx->stream_tail && Np - (J + W) <= tail_rows);
+      factor_panel(ctx, sp, J, W, co_mode == 2 || (co_mode == 1 && beside_bulk));
       next_col_done = false;
     }
     GPAK_HIP(hipEventRecord(EF[b], sp));
