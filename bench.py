@@ -92,7 +92,7 @@ def cpu_baseline(n_full, sample_n):
         "sample": (f"N={sample_n} reference sequence (expansion Gram + IRLS/Brent: {info.n_chol} Cholesky, "
                    f"{info.n_gemv} GEMV) measured {step_ref:.2f} s/step, "
                    f"{'SciPy-OpenBLAS dpotrf/dtrsm/dgemv' if lapack else 'in-repo blocked C'} on {cores} threads; "
-                   f"scaled to N={n_full} by (N_s/N)^3"),
+                   + (f"scaled to N={n_full} by (N_s/N)^3" if sample_n != n_full else "full size, no scaling")),
         "sample_n": sample_n,
         "sample_s_per_step": step_ref,
         "lean_value": scale / step_lean,
@@ -292,11 +292,29 @@ def run_single(args):
         out["n65536"] = {"N": 65536, "steps_per_s": 2 / w6, "ms_per_step": w6 / 2 * 1e3, "nlz": nlz6,
                          "factor_ms": ph6["factor_ms"] / 2,
                          "whole_factor_frac": (65536 ** 3 / 3.0) / (ph6["factor_ms"] / 2 * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+    if args.config2 and N == 32768:
+        # BASELINE.json configs[1]: N=8192 Gram + Cholesky on one GPU against the CPU path -- small enough for the CPU
+        # leg to run at FULL size (no (N_s/N)^3 scaling), which cpu_baseline() does below
+        X2, y2 = synth.drillholes(args.config2)
+        g.set_train(X2, y2)
+        w2, nlz2, ph2, _ = _timed_steps(g, mode, 20, 3)
+        e0, b0, s0 = params_for_step(0)          # the parameters the CPU leg uses: same inputs, comparable nlZ
+        g.set_params(e0, b0, s0, mode)
+        out["config2"] = {"N": args.config2, "steps_per_s": 20 / w2, "ms_per_step": w2 / 20 * 1e3,
+                          "nlz_step0_params": g.logLikelihood(),
+                          "factor_ms": ph2["factor_ms"] / 20, "gram_ms": ph2["gram_ms"] / 20}
     g.close()
     if args.config3 and N == 32768:
         out["config3"] = config3(args.config3, N)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(N, args.cpu_n)
+        if "config2" in out:
+            c2 = cpu_baseline(args.config2, args.config2)
+            out["config2"]["cpu"] = {"s_per_step": c2["sample_s_per_step"], "lean_s_per_step": c2["lean_sample_s_per_step"],
+                                     "cores": c2["cores"], "kind": c2["kind"], "sample": c2["sample"],
+                                     "nlz_step0_params": c2["nlz_sample"]}
+            out["config2"]["nlz_rel_diff_gpu_cpu"] = abs(out["config2"]["nlz_step0_params"] - c2["nlz_sample"]) / abs(c2["nlz_sample"])
+            out["config2"]["gpu_over_cpu"] = c2["sample_s_per_step"] / (out["config2"]["ms_per_step"] * 1e-3)
     return out
 
 
@@ -314,6 +332,8 @@ def main():
     ap.add_argument("--grad", type=int, default=0, help="also time this many GradLL evaluations (config 3)")
     ap.add_argument("--calibrate", action="store_true", default=True)
     ap.add_argument("--no-n65536", action="store_true", help="skip the N=65536 sub-run (north_star's scaling size)")
+    ap.add_argument("--config2", type=int, default=8192, help="size of the configs[1] sub-run (GPU step and the CPU "
+                                                               "reference sequence at full size; 0 = skip)")
     ap.add_argument("--config3", type=int, default=2, help="L-BFGS iterations of the configs[2] sub-run through the CLI "
                                                             "(N=32768 only; 0 = skip)")
     ap.add_argument("--profile-tag", default=os.environ.get("GPAK_PROFILE_TAG", "r02"),

@@ -66,12 +66,16 @@ int gpak_dev_fill_b(void *stream, const double *u, int cap, int n, int Np, int J
   return status();
 }
 
-int gpak_dev_factor_panel(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info) {
+int gpak_dev_factor_panel_co(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info,
+                             int coresident) {
   // virtual bases: global (row, column) addressing that only ever touches columns [J, J+W)
   double *Mv = blk - (size_t)J * ld;
   double *invv = inv - (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE;
-  gpak_factor_panel((hipStream_t)stream, Mv, ld, Np, J, W, invv, info, true);  // caller's inv may be uninitialised
+  gpak_factor_panel((hipStream_t)stream, Mv, ld, Np, J, W, invv, info, true, coresident != 0);  // caller's inv may be uninitialised
   return status();
+}
+int gpak_dev_factor_panel(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info) {
+  return gpak_dev_factor_panel_co(stream, blk, ld, Np, J, W, inv, info, 0);
 }
 
 int gpak_dev_update_block(void *stream, const double *panel, long ldp, int prow0, int W, double *blk, long ld,

@@ -18,6 +18,7 @@
 // touch a block column at once.  Every rank keeps every packed panel (rows from the diagonal block down) and
 // the inverted diagonal blocks, so both triangular solves run locally with no communication.
 #include <dlfcn.h>
+#include <atomic>
 
 #include <chrono>
 #include <cmath>
@@ -82,6 +83,12 @@ int he_zero(void *, void *st, void *dst, size_t bytes) {
 int he_copy(void *, void *st, void *dst, const void *src, size_t bytes) {
   return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)st) == hipSuccess ? GPAK_OK : GPAK_EHIP;
 }
+// set once a bulk stream had to be created WITHOUT a CU mask: its trailing updates may then hold two 210-VGPR waves on
+// every SIMD of the chip, and the panel stream's 128 x 128 block kernel must be the build that fits beside them
+std::atomic<int> g_he_bulk_unmasked{0};
+int he_factor_panel(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info) {
+  return gpak_dev_factor_panel_co(stream, blk, ld, Np, J, W, inv, info, g_he_bulk_unmasked.load(std::memory_order_relaxed));
+}
 void *he_stream_create(void *self, int kind) {
   HipEngineState *s = (HipEngineState *)self;
   hipStream_t st = nullptr;
@@ -94,6 +101,7 @@ void *he_stream_create(void *self, int kind) {
     s->mask_failed = true;   // e.g. a partitioned device: an ordinary stream, only slower
   }
   if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, kind == 0 ? lo : hi) != hipSuccess) return nullptr;
+  if (kind == 0) g_he_bulk_unmasked.store(1, std::memory_order_relaxed);
   return st;
 }
 void he_stream_destroy(void *, void *st) { if (st) hipStreamDestroy((hipStream_t)st); }
@@ -126,7 +134,7 @@ void fill_hip_engine(gpak_dist_engine &e, HipEngineState *st) {
   e.stream_create = he_stream_create; e.stream_destroy = he_stream_destroy;
   e.event_create = he_event_create; e.event_destroy = he_event_destroy; e.event_record = he_event_record;
   e.stream_wait_event = he_stream_wait_event; e.stream_sync = he_stream_sync; e.event_elapsed_ms = he_event_elapsed;
-  e.transform = gpak_dev_transform; e.fill_b = gpak_dev_fill_b; e.factor_panel = gpak_dev_factor_panel;
+  e.transform = gpak_dev_transform; e.fill_b = gpak_dev_fill_b; e.factor_panel = he_factor_panel;
   e.update_block = gpak_dev_update_block; e.update_cyclic = gpak_dev_update_cyclic;
   e.trsv_fwd_block = gpak_dev_trsv_fwd_block; e.trsv_bwd_packed = gpak_dev_trsv_bwd_packed;
   e.diag_inverse = gpak_dev_diag_inverse; e.logdiag_block = gpak_dev_logdiag_block; e.kmatvec = gpak_dev_kmatvec;

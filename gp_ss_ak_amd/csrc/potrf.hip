@@ -475,6 +475,9 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
                                hipFuncAttributeMaxDynamicSharedMemorySize, GPAK_POTRF_LDS_BYTES) == hipSuccess;
   }();
   (void)attr_ok;
+  // GPAK_POTRF_CO: 0 = always the 8-wave build, 2 = always the co-resident 4-wave build, 1 / unset = as the caller asks
+  static const int co_mode = getenv("GPAK_POTRF_CO") ? atoi(getenv("GPAK_POTRF_CO")) : 1;
+  if (co_mode != 1) co = co_mode == 2;
   if (co) hipLaunchKernelGGL(gpak_potrf128_co_f64, dim3(1), dim3(256), GPAK_POTRF_LDS_BYTES, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
   else hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(512), GPAK_POTRF_LDS_BYTES, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
 }
@@ -622,9 +625,6 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   // N=32768 -- the four K=128 products re-read and re-write the column four times and the chain gains nothing
   // measurable; off unless GPAK_SUB_NEXT=1 (kept: the multi-GPU schedule is built the same way and tests compare)
   static const bool sub_next = getenv("GPAK_SUB_NEXT") && atoi(getenv("GPAK_SUB_NEXT")) != 0;
-  // GPAK_POTRF_CO: 0 = always the 8-wave potrf128, 1 (default) = the co-resident 4-wave one beside unmasked bulk
-  // updates, 2 = always the 4-wave one
-  static const int co_mode = getenv("GPAK_POTRF_CO") ? atoi(getenv("GPAK_POTRF_CO")) : 1;
   bool next_col_done = false;   // the next block column already has this panel's update (applied per sub-panel)
   for (int b = 0; b < nJ; b++) {
     const int J = Js[b], W = Js[b + 1] - J;
@@ -638,7 +638,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
       // panel b is factored while the bulk update of panel b-1 (rows >= J + W) runs: on the unmasked stream that
       // update holds two 210-VGPR waves on every SIMD of the chip, and only the 4-wave, 80-VGPR potrf128 fits beside it
       const bool beside_bulk = ctx->lookahead && b > 0 && !(ctx->stream_tail && Np - (J + W) <= tail_rows);
-      factor_panel(ctx, sp, J, W, co_mode == 2 || (co_mode == 1 && beside_bulk));
+      factor_panel(ctx, sp, J, W, beside_bulk);
       next_col_done = false;
     }
     GPAK_HIP(hipEventRecord(EF[b], sp));

@@ -36,6 +36,11 @@ int gpak_dev_fill_b(void *stream, const double *u, int cap, int n, int Np, int J
  * of each 128 x 128 diagonal block).  *info (device int, pre-set to INT_MAX by the caller)
  * gets the minimum failing global column (1-based) if the block is not positive definite. */
 int gpak_dev_factor_panel(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info);
+/* The same with a placement hint: coresident != 0 selects the 4-wave / 80-VGPR build of the 128 x 128 block kernel,
+ * which fits on a compute unit beside two resident trailing-update workgroups; use it when the bulk update runs on a
+ * stream that may occupy every compute unit (no CU mask).  Results are identical. */
+int gpak_dev_factor_panel_co(void *stream, double *blk, long ld, int Np, int J, int W, double *inv, int *info,
+                             int coresident);
 
 /* Trailing update of an owned block column [Jc, Jc+Wc), Jc > J, with the factored panel of
  * [J, J+W) received from its owner.  `panel` holds rows [J+W.., Np) of that block column packed
