@@ -328,8 +328,15 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
         for (int n2 = 0; n2 < 2; n2++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            d2 v = {fma(alpha, acc[2 * h][2 * nh + n2][r], beta * c[n2][r].x),
-                    fma(alpha, acc[2 * h + 1][2 * nh + n2][r], beta * c[n2][r].y)};
+            d2 v;
+            if (alpha == -1.0 && beta == 1.0) {
+              // every update of the factorisation: c - acc is the same number as fma(-1, acc, 1 * c) in one fp64
+              // instruction instead of two (the FMA units these share with the MFMAs are the kernel's bottleneck)
+              v = (d2){c[n2][r].x - acc[2 * h][2 * nh + n2][r], c[n2][r].y - acc[2 * h + 1][2 * nh + n2][r]};
+            } else {
+              v = (d2){fma(alpha, acc[2 * h][2 * nh + n2][r], beta * c[n2][r].x),
+                       fma(alpha, acc[2 * h + 1][2 * nh + n2][r], beta * c[n2][r].y)};
+            }
             *reinterpret_cast<d2 *>(Cg + 32 * h + RS_COL(2 * nh + n2, r)) = v;
           }
       }
@@ -426,13 +433,18 @@ __global__ __launch_bounds__(256 * WROWS) void gpak_gemm_nt_f64_rs32(int K, doub
         d2 v = {alpha * acc[0][ni][r4], alpha * acc[1][ni][r4]};
         if (beta != 0.0) {
           const d2 c = *p;
-          v.x = fma(alpha, acc[0][ni][r4], beta * c.x);
-          v.y = fma(alpha, acc[1][ni][r4], beta * c.y);
+          if (alpha == -1.0 && beta == 1.0) {   // the in-panel update: one fp64 instruction per element, same number
+            v.x = c.x - acc[0][ni][r4];
+            v.y = c.y - acc[1][ni][r4];
+          } else {
+            v.x = fma(alpha, acc[0][ni][r4], beta * c.x);
+            v.y = fma(alpha, acc[1][ni][r4], beta * c.y);
+          }
         }
         *p = v;
       } else {
         double v = alpha * acc[0][ni][r4];
-        if (beta != 0.0) v = fma(alpha, acc[0][ni][r4], beta * *p);
+        if (beta != 0.0) v = (alpha == -1.0 && beta == 1.0) ? *p - acc[0][ni][r4] : fma(alpha, acc[0][ni][r4], beta * *p);
         *p = v;
       }
     }
