@@ -26,30 +26,24 @@ __device__ __forceinline__ double gpak_rdlane(double v, int l) {
 }
 
 // LDS image of the 128x128 block: only the 36 lower 16x16 tiles, each column-major with
-// leading dimension 16 (tile (rt,ct), ct<=rt, at slot rt(rt+1)/2+ct).  73,728 B -- small
-// enough to sit on a CU beside one resident trailing-update workgroup (72 KiB), which is what
-// lets the look-ahead panel actually start while the bulk update runs (a 150 KiB kernel is
-// starved until the whole GEMM grid has drained).  A 16-double tile column is 32 banks wide,
+// leading dimension 16 (tile (rt,ct), ct<=rt, at slot rt(rt+1)/2+ct).  A 16-double tile column is 32 banks wide,
 // so an MFMA fragment read (16 rows x 4 k) is conflict-free.
 __device__ __forceinline__ int gpak_tix(int rt, int ct, int i, int k) {
   return ((rt * (rt + 1) / 2 + ct) << 8) + (k << 4) + i;
 }
 
-// One workgroup (4 waves) factors the 128x128 block held in LDS, 16 columns at a time.
-//   diagonal 16x16 block (wave 0, in registers): lane i < 16 holds row i of the block, lanes
-//     16..31 hold the rows of a 16x16 IDENTITY.  Right-looking column operations (scale column
-//     j by 1/sqrt(pivot) -- v_rsq_f64 + two Newton steps, no divisions -- then column k -=
-//     column j * L[k][j], L[k][j] broadcast with v_readlane) turn the first 16 lanes into L and
-//     the identity rows into L^-T: the block's inverse costs no extra instruction.  The inverse
-//     is parked (transposed) in the unused strictly-upper half of the same LDS tile.
-//   panel  P := P * inv(D)^T  and trailing update  C -= P P^T: v_mfma_f64_16x16x4_f64 with
-//     operands read from LDS, several independent tiles in flight per wave.
-//   overlap: wave 0 updates the NEXT diagonal tile first and factors it while waves 1-3 finish
-//     the rest of the trailing update, so the serial 16x16 factorisations hide behind MFMA work.
-// Then the 128x128 inverse by block forward substitution, one block column per wave pass: a
-// finished 16x16 accumulator tile is used directly as the B operand of the next MFMA (the f64
-// 16x16x4 D layout row=(lane>>4)+4*reg, col=lane&15 is the B-fragment layout of k-step `reg`),
-// so the inverse never goes back through LDS.
+// One workgroup (8 waves, or 4 in the co-resident build) factors the 128x128 block held in LDS, 16 columns at a
+// time, and returns L, L^-1 and L^-T (DESIGN.md section 4.2 has the measurements behind every choice below).
+//   diagonal 16x16 block (wave 0, vector pipe): lane c < 16 owns column c of the symmetric block, lanes 16..31 the
+//     columns of an identity; pivots by v_readlane, 1/sqrt by v_rsq_f64 + a coupled Goldschmidt iteration; the same
+//     row operations turn the identity into the block's inverse.
+//   panel  P := P * inv(D)^T  and trailing update  C -= P P^T: v_mfma_f64_16x16x4_f64 with operands read from LDS,
+//     accumulators kept transposed (conflict-free), several independent tiles in flight per wave.
+//   overlap: wave 0 updates the NEXT diagonal tile first and factors it while the helper waves (on the other three
+//     SIMDs: f64 MFMAs and f64 vector instructions share the FMA units) finish the trailing update.
+//   the 128x128 inverse rides along: block forward substitution on R = I in right-looking form, phase A by the waves
+//     without a panel tile, phase B dealt to the helpers, kept transposed in a second LDS array.
+//   results are stored as soon as they are final (column kb of L, row kb of the inverse during step kb).
 //   A      : block in global memory (column-major, ld); lower triangle is read
 //   inv    : 2 x (128x128) doubles: inv(L) then inv(L)^T, column-major ld 128
 //   col0   : global column of the block (for the not-positive-definite report)
