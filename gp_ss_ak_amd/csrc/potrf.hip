@@ -12,6 +12,7 @@
 //     [gemm_nt]     trailing update of everything right of the outer block (K = nb_outer):
 //                   the N^3/3 term, MFMA-bound.
 #include <algorithm>
+#include <atomic>
 
 #include "gpak_internal.h"
 
@@ -462,13 +463,21 @@ void gpak_potrf128_co_f64(double *A, long ld, double *__restrict__ inv, int col0
 }
 
 void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv, bool co) {
-  static const bool attr_ok = [] {   // 132 KiB of dynamic LDS needs the opt-in, once per kernel
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(gpak_potrf128_f64), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               GPAK_POTRF_LDS_BYTES) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void *>(gpak_potrf128_co_f64),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GPAK_POTRF_LDS_BYTES) == hipSuccess;
-  }();
-  (void)attr_ok;
+  // 132 KiB of dynamic LDS needs the opt-in, once per kernel AND per device (a thread group drives several devices
+  // from one process)
+  {
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gpak_potrf128_f64), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GPAK_POTRF_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gpak_potrf128_co_f64),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GPAK_POTRF_LDS_BYTES);
+      done_mask.fetch_or(bit, std::memory_order_release);
+    }
+  }
   // GPAK_POTRF_CO: 0 = always the 8-wave build, 2 = always the co-resident 4-wave build, 1 / unset = as the caller asks
   static const int co_mode = getenv("GPAK_POTRF_CO") ? atoi(getenv("GPAK_POTRF_CO")) : 1;
   if (co_mode != 1) co = co_mode == 2;
