@@ -292,9 +292,14 @@ def test_alternative_kernels_give_the_same_step():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     vals = {}
     for name, env in (("default", {}), ("lds", {"GPAK_GEMM": "lds"}), ("nomask", {"GPAK_TAIL_MASK": "0"}),
-                      ("nosmall", {"GPAK_GEMM_SMALL": "0"})):
+                      ("nosmall", {"GPAK_GEMM_SMALL": "0"}),
+                      # the two builds of the 128x128 block kernel (8 waves / 4 waves at 80 VGPRs) and the three
+                      # workgroup heights of the panel-chain GEMM
+                      ("potrf_co_never", {"GPAK_POTRF_CO": "0"}), ("potrf_co_always", {"GPAK_POTRF_CO": "2"}),
+                      ("rows64", {"GPAK_GEMM_SMALL_ROWS": "64"}), ("rows32", {"GPAK_GEMM_SMALL_ROWS": "32"}),
+                      ("no_lookahead", {"GPAK_LOOKAHEAD": "0"})):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--size",
-                              "6000", "--no-cpu"], env=dict(os.environ, **env), cwd=root, stdout=subprocess.PIPE,
+                              "6000", "--no-cpu", "--no-n65536"], env=dict(os.environ, **env), cwd=root, stdout=subprocess.PIPE,
                              stderr=subprocess.PIPE, timeout=600)
         assert out.returncode == 0, out.stderr.decode()[-2000:]
         vals[name] = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])["nlz"]

@@ -7,7 +7,7 @@ import bench
 for N in [int(a) for a in sys.argv[1:]] or [8192, 16384, 32768]:
     X, y = synth.drillholes(N)
     g = gpak.Gpak(0)
-    g.set_option(gpak.OPT_PROFILE, 1)
+    g.set_option(gpak.OPT_PROFILE, int(os.environ.get('PROFILE', '1')))
     if os.environ.get('NB_OUTER'):
         g.set_option(gpak.OPT_NB_OUTER, int(os.environ['NB_OUTER']))
     g.set_train(X, y)
