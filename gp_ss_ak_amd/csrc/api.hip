@@ -431,7 +431,7 @@ static int ensure_nlz(gpak_ctx *ctx) {
   double *scratch = ctx->dWork + 4 * (size_t)ctx->Np;  // 64 * Np doubles available
   GPAK_HIP(hipEventRecord(ctx->ev[5], st));
   int splits = gpak_kmatvec_splits(ctx->N, ctx->N);
-  gpak_launch_kmatvec(st, ctx->U, 0, ctx->N, ctx->dAlpha, ctx->U, ctx->kp, scratch, splits, f);  // f = K*Alpha
+  gpak_launch_kmatvec(st, ctx->U, 0, ctx->N, ctx->dAlpha, ctx->U, ctx->kp, scratch, splits, f, 64);  // f = K*Alpha
   GPAK_HIP(hipEventRecord(ctx->ev[8], st));
   if (ctx->kp.white != 0.0) gpak_launch_axpy(st, ctx->N, ctx->kp.white, ctx->dAlpha, f);  // Kern_White diagonal
   gpak_launch_logdet(st, ctx->N, ctx->dM, ctx->ld, ctx->dRed);

@@ -232,10 +232,11 @@ void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, in
                       const KernParams &kp, double scale, double diag, double pad_diag, int lower_only,
                       double *C, long ld, double *D2out, int col_off = 0);
 // out_j = sum_i w_i K(P_i, Q_j), j < Q.n   (fused Gram-matvec; K never stored).
-// scratch holds splits * Q.cap doubles.
+// scratch holds max(splits, scratch_rows) * Q.cap doubles (scratch_rows: what the caller really has; the symmetric
+// kernel for P == Q needs one row per 512 points).
 int gpak_kmatvec_splits(int nP, int nQ);
 void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, int p_off, int np, const double *w, const DevPoints &Q,
-                         const KernParams &kp, double *scratch, int splits, double *out);
+                         const KernParams &kp, double *scratch, int splits, double *out, int scratch_rows = 0);
 void gpak_launch_sum_splits(hipStream_t st, const double *part, int part_ld, int splits, int n, double *out);
 int gpak_alloc_points(gpak_ctx *ctx, DevPoints &p, int cap);
 void gpak_pooled_mean(const double *s1, long n, const double *s2, long m, double *mu);

@@ -371,13 +371,140 @@ __global__ __launch_bounds__(256) void gpak_kmatvec1_part_f64(const double *__re
     if (ok[q]) part[(size_t)blockIdx.y * part_ld + j[q]] = fma(bias, wsum, acc[q]);
 }
 
+// ---------------------------------------------------------------------------------------
+// f = K w with BOTH vectors over the same points (the nlZ's f = K alpha): K is symmetric, so every kernel value is
+// evaluated once and used twice -- N^2/2 evaluations instead of N^2 of a kernel that is bound by exactly those.
+// Macro blocks of KSYM_G * 256 points; one workgroup per pair (mi <= mj).  Thread t owns KSYM_G columns of macro block
+// mj (as above: coordinates in registers, one accumulator each); the rows of macro block mi come through LDS 256 at a
+// time.  Off the diagonal a value k(i, j) also feeds row i: the thread's w_j k summed over its columns, then summed
+// over the wave's 64 lanes -- 16 rows at a time through an LDS transpose (16 writes, 16 reads, 15 adds and two
+// quad-permute steps per lane and 16 rows: 3.3 instructions per row; a DPP reduction per row costs 22, a fifth of the
+// evaluations it accompanies) -- and after 256 rows the four waves' totals go out.
+// part[r][x] receives the contribution of the pair (x's macro block, r) to f[x] -- the column sums of pair (r, m) for
+// r <= m, the row sums of pair (m, r) for r > m -- so f = the sum of the nbm rows of part (gpak_kmatvec_reduce_f64),
+// in a fixed order.  The diagonal pairs evaluate their full square and keep only the column sums.
+// KSYM_G = 2: 2080 workgroups at N = 32768 (4: 528, two waves per SIMD, slower).  Used from 32 macro blocks on
+// (N > 15872): below that the grid is too small (N = 8192: 0.45 ms against 0.10 ms for the plain kernel).
+// ---------------------------------------------------------------------------------------
+#define KSYM_G 2
+#define KSYM_MIN_BLOCKS 32
+__device__ __forceinline__ double gpak_quad_add(double v, const bool swap2) {
+  int lo = __double2loint(v), hi = __double2hiint(v), mlo, mhi;
+  if (!swap2) {   // quad_perm:[1,0,3,2]
+    mlo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); mhi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+  } else {        // quad_perm:[2,3,0,1]
+    mlo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); mhi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false);
+  }
+  return v + __hiloint2double(mhi, mlo);
+}
+
+template <int MODE, bool D4>
+__global__ __launch_bounds__(256) void gpak_kmatvec1_sym_f64(const double *__restrict__ P, int capP, int n,
+                                                              const double *__restrict__ w, double var2, double bias,
+                                                              double *__restrict__ part, int part_ld) {
+  __shared__ double sp[GPAK_PT + 1][KMV_CHUNK];
+  __shared__ double tab[GPAK_EXPTAB_N];
+  __shared__ double rw[4][KMV_CHUNK];
+  __shared__ double tr[4][16][65];   // one wave's 16 rows x 64 lanes, row stride 65: the transposed read is 2-way at worst
+  __shared__ double wred[256];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (t < GPAK_EXPTAB_N) tab[t] = gpak_exp2_tab[t];
+  int mi = blockIdx.x, mj = 0;
+  while (mi > mj) { mi -= mj + 1; mj++; }   // pair index -> (mi <= mj), scalar
+  const bool offdiag = mi != mj;
+  int j[KSYM_G];
+  double b[KSYM_G][GPAK_PT], wj[KSYM_G], acc[KSYM_G];
+  double wjsum = 0.0;
+#pragma unroll
+  for (int q = 0; q < KSYM_G; q++) {
+    j[q] = (mj * KSYM_G + q) * 256 + t;
+    const bool ok = j[q] < n;
+#pragma unroll
+    for (int c = 0; c < GPAK_PT; c++) b[q][c] = ok ? PARR(P, capP, 0, c)[j[q]] : 0.0;
+    wj[q] = ok ? w[j[q]] : 0.0;
+    wjsum += wj[q];
+    acc[q] = 0.0;
+  }
+  // W_j = the weights of the whole column macro block (the bias term of the row sums), summed in a fixed order
+  wred[t] = wjsum;
+  __syncthreads();
+  double Wj = 0.0;
+  for (int u = 0; u < 256; u++) Wj += wred[u];
+  double wsum = 0.0;
+  for (int ib = 0; ib < KSYM_G; ib++) {
+    const int i0 = (mi * KSYM_G + ib) * 256;
+    if (i0 >= n) break;   // uniform
+    const int i = i0 + t;
+    const bool v = i < n;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < GPAK_PT; c++) sp[c][t] = v ? PARR(P, capP, 0, c)[i] : 0.0;
+    sp[GPAK_PT][t] = v ? w[i] : 0.0;  // zero weight masks the tail
+    __syncthreads();
+    for (int k0 = 0; k0 < KMV_CHUNK; k0 += 16) {
+#pragma unroll 4
+      for (int kk = 0; kk < 16; kk++) {
+        const int k = k0 + kk;
+        const double p0 = sp[0][k], p1 = sp[1][k], p2 = sp[2][k], p3 = sp[3][k], p4 = sp[4][k], wk = sp[GPAK_PT][k];
+        wsum += wk;
+        double r = 0.0;
+#pragma unroll
+        for (int q = 0; q < KSYM_G; q++) {
+          const double kv = gpak_k1<MODE, D4>(p0, p1, p2, p3, p4, b[q][0], b[q][1], b[q][2], b[q][3], b[q][4], var2, 0.0, tab);
+          acc[q] = fma(wk, kv, acc[q]);
+          r = fma(wj[q], kv, r);
+        }
+        if (offdiag) tr[wv][kk][lane] = r;
+      }
+      if (offdiag) {
+        // lane l sums a quarter (l & 3) of row l >> 2; the wave's own LDS writes are in order before these reads
+        __builtin_amdgcn_wave_barrier();
+        const double *src = &tr[wv][lane >> 2][(lane & 3) * 16];
+        double s0 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) s0 += src[e];
+        s0 = gpak_quad_add(s0, false);
+        s0 = gpak_quad_add(s0, true);
+        if ((lane & 3) == 0) rw[wv][k0 + (lane >> 2)] = s0;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (offdiag) {
+      __syncthreads();
+      if (v) part[(size_t)mj * part_ld + i] = fma(bias, Wj, (rw[0][t] + rw[1][t]) + (rw[2][t] + rw[3][t]));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KSYM_G; q++)
+    if (j[q] < n) part[(size_t)mi * part_ld + j[q]] = fma(bias, wsum, acc[q]);
+}
+
 // source points [p_off, p_off + np) of P with weights w[0..np)
 void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, int p_off, int np, const double *w, const DevPoints &Q,
-                         const KernParams &kp, double *scratch, int splits, double *out) {
+                         const KernParams &kp, double *scratch, int splits, double *out, int scratch_rows) {
+  if (scratch_rows < splits) scratch_rows = splits;
   int per = (np + splits - 1) / splits;
   per = (per + KMV_CHUNK - 1) / KMV_CHUNK * KMV_CHUNK;
   dim3 grid((Q.n + 256 * KMV_COLS - 1) / (256 * KMV_COLS), splits);
   static const bool fast_off = getenv("GPAK_FILL_FAST") && atoi(getenv("GPAK_FILL_FAST")) == 0;
+  static const bool sym_off = getenv("GPAK_KMV_SYM") && atoi(getenv("GPAK_KMV_SYM")) == 0;
+  // the symmetric kernel: both vectors over the same points, a grid large enough to fill the chip, and its nbm partial
+  // rows fit into the scratch (scratch_rows * Q.cap doubles; at least the `splits` rows every caller provides)
+  const int nbm = (Q.n + 256 * KSYM_G - 1) / (256 * KSYM_G);
+  if (kp.nterms == 1 && kp.term[0].profile == GPAK_PROFILE_EXPSQRT && !fast_off && !sym_off && P.base == Q.base &&
+      p_off == 0 && np == Q.n && nbm >= KSYM_MIN_BLOCKS && nbm <= scratch_rows) {
+    const dim3 sgrid((unsigned)(nbm * (nbm + 1) / 2));
+#define GPAK_KMVS(MODE_, D4_)                                                                                          \
+  hipLaunchKernelGGL((gpak_kmatvec1_sym_f64<MODE_, D4_>), sgrid, dim3(256), 0, st, P.base, P.cap, np, w,                 \
+                     kp.term[0].var2, kp.bias, scratch, Q.cap)
+    const bool d4 = kp.d == 4;
+    if (kp.mode == GPAK_DIST_DIRECT) { if (d4) GPAK_KMVS(GPAK_DIST_DIRECT, true); else GPAK_KMVS(GPAK_DIST_DIRECT, false); }
+    else { if (d4) GPAK_KMVS(GPAK_DIST_EXPANSION, true); else GPAK_KMVS(GPAK_DIST_EXPANSION, false); }
+#undef GPAK_KMVS
+    hipLaunchKernelGGL(gpak_kmatvec_reduce_f64, dim3((Q.n + 255) / 256), dim3(256), 0, st, scratch, Q.cap, nbm, Q.n, out);
+    return;
+  }
   if (kp.nterms == 1 && kp.term[0].profile == GPAK_PROFILE_EXPSQRT && !fast_off) {
 #define GPAK_KMV1(MODE_, D4_)                                                                                          \
   hipLaunchKernelGGL((gpak_kmatvec1_part_f64<MODE_, D4_>), grid, dim3(256), 0, st, P.base, P.cap, np, p_off, w, per, Q.base, \

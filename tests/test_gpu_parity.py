@@ -307,6 +307,40 @@ def test_alternative_kernels_give_the_same_step():
         assert abs(v - vals["default"]) <= 1e-11 * abs(vals["default"]), (name, vals)
 
 
+@pytest.mark.parametrize("d", [3, 4])
+def test_symmetric_gram_matvec_matches_the_plain_one(d):
+    """f = K alpha on the symmetric pair kernel (N > 15872: every kernel value used for both of its entries) against
+    the plain N^2 kernel (GPAK_KMV_SYM=0), both distance forms, 3 and 4 columns, a ragged last macro block: the three
+    terms of the nlZ (quad = alpha' f / 2 and sumlp see every entry of f) agree to rounding.  The environment is read
+    once per process, hence subprocesses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import json, sys; sys.path.insert(0, %r)\n"
+        "from gp_ss_ak_amd import gpak, synth\n"
+        "import numpy as np\n"
+        "N = 16000\n"
+        "X, y = (synth.drillholes4(N) if %d == 4 else synth.drillholes(N))\n"
+        "E = np.array(list(synth.DEFAULT_EXPANS), dtype=np.float64)\n"
+        "g = gpak.Gpak(0); g.set_train(X, y); out = {}\n"
+        "for name, mode in (('direct', gpak.DIST_DIRECT), ('expansion', gpak.DIST_EXPANSION)):\n"
+        "    g.set_params(E, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, mode)\n"
+        "    out[name] = list(g.nlz_terms()) + [g.logLikelihood()]\n"
+        "print(json.dumps(out))\n") % (root, d)
+    res = {}
+    for name, env in (("sym", {}), ("plain", {"GPAK_KMV_SYM": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), cwd=root, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        res[name] = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    for mode in ("direct", "expansion"):
+        for a, b in zip(res["sym"][mode], res["plain"][mode]):
+            assert abs(a - b) <= 1e-11 * abs(b), (mode, res)
+
+
 def test_nan_input_is_not_hidden(gp):
     """A NaN coordinate must surface (NaN entries in K, Chol_fail -> NaN nlZ as at GP_Utils.cpp:1145-1158), not be
     turned into a finite number by the in-line sqrt/exp."""
