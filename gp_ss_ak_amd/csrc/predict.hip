@@ -156,16 +156,18 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   GPAK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int N = ctx->N, Np = ctx->Np;
-  int batch = 16384;  // measured at N=32768: 4096 -> 58 (f64) / 91 (f32) TFLOP/s, 16384 -> 70.5 / 100.5
+  // test points per batch, measured at N=32768: 4096 -> 58 (f64) / 91 (f32) TFLOP/s, 16384 -> 71.6 / 115.4,
+  // 32768 -> 71.7 / 118.7, 65536 -> 71.8 / 119.7: the fp32 path takes the larger batch
+  const bool f32 = ctx->precision == GPAK_F32;
+  int batch = f32 ? 65536 : 16384;
   if (const char *e = getenv("GPAK_PRED_BATCH")) batch = std::max(2 * PB, atoi(e) / (2 * PB) * (2 * PB));
   // keep the cross-kernel batch under ~8 GiB
-  while (batch > 2 * PB && (size_t)batch * Np * sizeof(double) > ((size_t)8 << 30)) batch /= 2;
+  while (batch > 2 * PB && (size_t)batch * Np * (f32 ? sizeof(float) : sizeof(double)) > ((size_t)8 << 30)) batch /= 2;
   batch = batch / (2 * PB) * (2 * PB);
   long Mp = (M + 2 * PB - 1) / (2 * PB) * (2 * PB);   // 256-row granularity: the fp32 GEMM's workgroup tile
   const int cap = (int)std::min<long>(Mp, batch);
   int rc = ensure_predict_bufs(ctx, cap, var != nullptr);
   if (rc) return rc;
-  const bool f32 = ctx->precision == GPAK_F32;
   if (f32 && var && (rc = ensure_f32_factor(ctx))) return rc;
   hipEvent_t e0 = ctx->ev[5], e1 = ctx->ev[6];
   GPAK_HIP(hipEventRecord(e0, st));
