@@ -54,7 +54,10 @@ __global__ void valu_diag(long long *out, const double *Ain, double *Lout, unsig
       for (int i = r + 1; i < 16; i++) { const double ui = rdlane(xr, i); x[i] = fma(-ui, xr, x[i]); }
     } else {
       // u_i comes from the S row of lanes: broadcast inside row 0 by DPP, to the identity lanes by one more step
-      const double xs = __shfl(xr, l15, 64);   // every 16-lane row gets the S row's values (1 LDS-crossbar op per pivot)
+      // row 1 (the identity lanes) gets row 0's values: v_permlane16_swap (gfx950), one per 32-bit half
+      const int xlo = __double2loint(xr), xhi = __double2hiint(xr);
+      const double xs = __hiloint2double(__builtin_amdgcn_permlane16_swap(xhi, xhi, false, false)[0],
+                                         __builtin_amdgcn_permlane16_swap(xlo, xlo, false, false)[0]);
 #define BC(i_) if (i_ > r) { const double ui = rowbcast<i_>(xs); x[i_] = fma(-ui, xr, x[i_]); }
       BC(1) BC(2) BC(3) BC(4) BC(5) BC(6) BC(7) BC(8) BC(9) BC(10) BC(11) BC(12) BC(13) BC(14) BC(15)
 #undef BC
@@ -172,7 +175,7 @@ int main() {
         resi = fmax(resi, fabs(w - (i == j ? 1.0 : 0.0)));
       }
       printf("VALU 16x16 factor+inverse (%s): %lld cycles (%.0f per pivot), max |LL^T - A| %.2e, max |L Linv - I| %.2e\n",
-             mode == 1 ? "DPP row_newbcast" : mode == 0 ? "v_readlane" : mode == 2 ? "v_readlane, waves 1-7 on MFMAs" : mode == 3 ? "v_readlane, waves 1-3 (other SIMDs) on MFMAs" : mode == 4 ? "v_readlane, wave 4 (same SIMD) on MFMAs" : "v_readlane, waves 1-3,5-7 on MFMAs", c, c / 16.0, res, resi);
+             mode == 1 ? "DPP row_newbcast + permlane16_swap" : mode == 0 ? "v_readlane" : mode == 2 ? "v_readlane, waves 1-7 on MFMAs" : mode == 3 ? "v_readlane, waves 1-3 (other SIMDs) on MFMAs" : mode == 4 ? "v_readlane, wave 4 (same SIMD) on MFMAs" : "v_readlane, waves 1-3,5-7 on MFMAs", c, c / 16.0, res, resi);
     }
   }
   return 0;
