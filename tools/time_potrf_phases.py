@@ -19,9 +19,8 @@ lib.gpak_dev_potrf_timing(out)
 t = list(out)
 print("load", t[1]-t[0], "diag0", t[2]-t[1])
 for kb in range(7):
-    print("kb", kb, "panel-phase(incl barrier)", t[3+4*kb]-(t[2] if kb==0 else t[6+4*(kb-1)]), "tile0", t[4+4*kb]-t[3+4*kb], "diag", t[5+4*kb]-t[4+4*kb], "wait-others", t[6+4*kb]-t[5+4*kb])
-print("store", t[33]-t[32], "inverse", t[34]-t[33], "total", t[34]-t[0])
-print("kb0 helpers rel. to slot start", "w1 start", t[44]-t[3], "trailing done", t[40]-t[3], "phase_b done", t[41]-t[3], "| w4 stores", t[42]-t[3], t[43]-t[3], "| w0 diag done", t[5]-t[3], "barrier", t[6]-t[3])
-b = t[6+4*2]
-print("kb3 panel phase, wave 1 rel. to the barrier before it (t==0 stamp): enter", t[45]-b, "operands in", t[46]-b, "mfma done", t[47]-b, "stored", t[48]-b, "after barrier", t[49]-b, "wave0 after barrier", t[3+4*3]-b)
-print("diag(3): tile-0 update", t[50]-t[4+4*2], "column load", t[51]-t[50], "pivots 0-7", t[52]-t[51], "pivots 8-15", t[53]-t[52], "write", t[54]-t[53])
+    print("kb", kb, "panel-phase(incl barrier)", t[3+4*kb]-(t[2] if kb==0 else t[6+4*(kb-1)]), "next diagonal block (wave 0)", t[5+4*kb]-t[3+4*kb], "wait-others", t[6+4*kb]-t[5+4*kb])
+print("total", t[34]-t[0], "cycles")
+print("last row of the inverse + final stores", t[34]-t[33])
+print("kb0 helper wave 1 rel. to its slot's start: start", t[44]-t[3], "trailing tiles done", t[40]-t[3], "phase B done", t[41]-t[3], "| wave 0's block done", t[5]-t[3], "barrier", t[6]-t[3])
+print("block 3 (wave 0): tile-0 update", t[50]-t[4+4*2], "column read", t[51]-t[50], "pivots 0-7", t[52]-t[51], "pivots 8-15", t[53]-t[52], "write", t[54]-t[53])
