@@ -56,6 +56,7 @@ struct gpak_ctx {
   hipStream_t stream = nullptr;     // main stream: fill, bulk trailing updates, solves
   hipStream_t stream_hi = nullptr;  // high-priority stream: panel factorisation (look-ahead)
   hipStream_t stream_tail = nullptr;  // CU-masked copy of the main stream for the tail's bulk updates (optional)
+  hipStream_t stream_bulk = nullptr;  // the bulk updates' own queue before the tail: created like stream_tail but with every CU enabled (optional)
   hipStream_t stream_fs = nullptr;  // forward substitution riding along with the factorisation, off the panel chain
   hipStream_t stream_x = nullptr;   // tail: K=128 updates of the next block column, sub-panel by sub-panel
   std::string err;

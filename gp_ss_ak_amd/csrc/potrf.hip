@@ -674,7 +674,8 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
     if (J2 < Np) {
       // chain-bound tail: the bulk update is off the critical path there; on the CU-masked stream it leaves
       // idle compute units to potrf128 and the small panel products
-      hipStream_t su_b = (ctx->stream_tail && ctx->lookahead && Np - J2 <= tail_rows) ? ctx->stream_tail : ctx->stream;
+      hipStream_t su_b = (ctx->stream_tail && ctx->lookahead && Np - J2 <= tail_rows) ? ctx->stream_tail
+                         : (ctx->stream_bulk && ctx->lookahead) ? ctx->stream_bulk : ctx->stream;
       if (su_b != su) {                       // keep the order of successive bulk updates across the two streams
         GPAK_HIP(hipEventRecord(Eorder, su));
         GPAK_HIP(hipStreamWaitEvent(su_b, Eorder, 0));
