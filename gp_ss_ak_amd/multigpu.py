@@ -151,6 +151,12 @@ class HipEngine:
         self._chk(self.lib.gpak_dev_factor_panel(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(inv),
                                                  self._p(info)), "gpak_dev_factor_panel")
 
+    def factor_panel_co(self, blk, ld, Np, J, W, inv, info, coresident):
+        """gpak_dev_factor_panel with the placement hint (coresident != 0: the 4-wave / 80-VGPR block kernel)."""
+        self.lib.gpak_dev_factor_panel_co.restype = C.c_int
+        self._chk(self.lib.gpak_dev_factor_panel_co(self._st(), self._p(blk), C.c_long(ld), Np, J, W, self._p(inv),
+                                                    self._p(info), int(coresident)), "gpak_dev_factor_panel_co")
+
     def update_block(self, panel, ldp, prow0, W, blk, ld, Np, Jc, Wc):
         self._chk(self.lib.gpak_dev_update_block(self._st(), self._p(panel), C.c_long(ldp), prow0, W, self._p(blk),
                                                  C.c_long(ld), Np, Jc, Wc), "gpak_dev_update_block")
