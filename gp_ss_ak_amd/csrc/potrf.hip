@@ -56,6 +56,8 @@ __device__ long long gpak_potrf_dbg[64];
 // that showed up in whichever phase came next
 #define GPAK_TS(i_) do { if (t == 0) gpak_ts_lds[i_] = (long long)__builtin_readcyclecounter(); } while (0)
 #define GPAK_TSW(w_, i_) do { if (t == 64 * (w_)) gpak_ts_lds[i_] = (long long)__builtin_readcyclecounter(); } while (0)
+// a stamp that first pins the sixteen registers of the diagonal block, so that the arithmetic before it cannot sink below it
+#define GPAK_TS_PIN(x_, i_) do { asm volatile("" : "+v"(x_[0]), "+v"(x_[1]), "+v"(x_[2]), "+v"(x_[3]), "+v"(x_[4]), "+v"(x_[5]), "+v"(x_[6]), "+v"(x_[7]), "+v"(x_[8]), "+v"(x_[9]), "+v"(x_[10]), "+v"(x_[11]), "+v"(x_[12]), "+v"(x_[13]), "+v"(x_[14]), "+v"(x_[15])); GPAK_TS(i_); } while (0)
 #define GPAK_TS_DECL long long *const gpak_ts_lds = reinterpret_cast<long long *>(SM + GPAK_POTRF_SM_DOUBLES + 28 * 256);
 #define GPAK_TS_FLUSH() do { __syncthreads(); if (t < 64) gpak_potrf_dbg[t] = gpak_ts_lds[t]; } while (0)
 extern "C" int gpak_dev_potrf_timing(long long *out) {
@@ -64,6 +66,7 @@ extern "C" int gpak_dev_potrf_timing(long long *out) {
 #else
 #define GPAK_TS(i_) do { } while (0)
 #define GPAK_TSW(w_, i_) do { } while (0)
+#define GPAK_TS_PIN(x_, i_) do { } while (0)
 #define GPAK_TS_DECL
 #define GPAK_TS_FLUSH() do { } while (0)
 #endif
@@ -293,10 +296,10 @@ __device__ __forceinline__ void gpak_potrf128_body(double *A, long ld, double *_
       x[i] = SM[(l4 == 0 ? gpak_tix(kb, kb, 0, 0) : ID0) + (i << 4) + l15];   // S[l15][i] = S[i][l15], or the identity
     }
     int bad = 16;   // first non-positive pivot of this block (branch-free: the 16 pivots stay one basic block)
-    if (kb == 3) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])); GPAK_TS(51); }
+    if (kb == 3) GPAK_TS_PIN(x, 51);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      if (kb == 3 && r == 8) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])); GPAK_TS(52); }
+      if (kb == 3 && r == 8) GPAK_TS_PIN(x, 52);
       double dv = gpak_rdlane(x[r], r);
       const bool ok = dv > 0.0;
       bad = min(bad, ok ? 16 : r);
@@ -320,7 +323,7 @@ __device__ __forceinline__ void gpak_potrf128_body(double *A, long ld, double *_
         x[i] = fma(-ui, xr, x[i]);
       }
     }
-    if (kb == 3) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])); GPAK_TS(53); }
+    if (kb == 3) GPAK_TS_PIN(x, 53);
     if (bad < 16 && lane == 0) atomicMin(info, col0 + 16 * kb + bad + 1);
     // lane c < 16: x[r] = L[c][r] for r <= c (beyond that: leftovers, which land in the tile's unused upper half);
     // lanes 16 + c: x[r] = (L^-1)[r][c], exact zeros for r < c.  One store per register, no per-register lane masks

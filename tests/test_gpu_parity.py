@@ -307,59 +307,70 @@ def test_alternative_kernels_give_the_same_step():
         assert abs(v - vals["default"]) <= 1e-11 * abs(vals["default"]), (name, vals)
 
 
-@pytest.mark.parametrize("coresident", [0, 1])
-def test_block_kernel_directly(coresident):
-    """gpak_potrf128_f64 (8 waves) and gpak_potrf128_co_f64 (4 waves, 80 VGPRs) on single 128 x 128 blocks through the
-    device-level C-ABI: L, L^-1 and L^-T against NumPy for a well- and an ill-conditioned block, junk in the upper
-    triangle ignored, both builds bit-identical, and the first non-positive pivot reported (1-based global column)."""
-    import torch
-    from gp_ss_ak_amd import multigpu
-    eng = multigpu.HipEngine(0)
-    rng = np.random.default_rng(3)
-    G = rng.normal(size=(128, 128))
-    blocks = {"well": G @ G.T + 128 * np.eye(128),
-              "ill": (G * np.logspace(0, -5, 128)) @ (G * np.logspace(0, -5, 128)).T + 1e-9 * np.eye(128)}
-    outs = {}
-    for name, A in blocks.items():
-        Ain = np.tril(A) + np.triu(rng.normal(size=(128, 128)) * 1e3, 1)      # the kernel reads the lower triangle only
-        blk = eng.from_numpy(np.asfortranarray(Ain).T.ravel().copy())
-        inv = eng.empty(2 * 128 * 128)
-        info = eng.zeros(4, dtype=torch.int32); info.fill_(0x7fffffff)
-        eng.factor_panel_co(blk, 128, 128, 0, 128, inv, info, coresident)
-        torch.cuda.synchronize()
-        L = np.tril(blk.cpu().numpy().reshape(128, 128).T)
-        iv = inv.cpu().numpy()
-        Li, LiT = iv[:128 * 128].reshape(128, 128).T, iv[128 * 128:].reshape(128, 128).T
-        Lref = np.linalg.cholesky(A)
-        scale = np.abs(Lref).max()
-        assert int(info.cpu()[0]) == 0x7fffffff
-        assert np.abs(L - Lref).max() <= (1e-12 if name == "well" else 1e-7) * scale
-        assert np.abs(L @ L.T - A).max() <= 1e-13 * np.abs(A).max()
-        assert np.abs(Li @ L - np.eye(128)).max() <= (1e-12 if name == "well" else 1e-6)
-        assert np.array_equal(LiT, Li.T)
-        out = blk.cpu().numpy().reshape(128, 128).T
-        tiles = np.kron(np.eye(8), np.ones((16, 16))) > 0                       # the diagonal 16 x 16 tiles
-        assert np.array_equal(np.triu(out, 1)[tiles], np.zeros(tiles.sum()))    # ... come back cleanly lower
-        above = np.triu(np.ones((128, 128)), 1) > 0
-        assert np.array_equal(out[above & ~tiles], Ain[above & ~tiles])         # the tiles above them are not touched
-        outs[name] = (L.copy(), Li.copy())
-    # not positive definite from column 70 (0-based) of a block that starts at global column 256
-    A = blocks["well"].copy()
-    A[70, 70] = -1.0
-    blk = eng.from_numpy(np.asfortranarray(A).T.ravel().copy())
-    big = eng.zeros(384 * 128)                                       # block column [256, 384) of a 384-row matrix
-    big.view(128, 384)[:, 256:] = blk.view(128, 128)
+_BLOCK_KERNEL_SCRIPT = r'''
+import hashlib, json, sys
+import numpy as np, torch
+from gp_ss_ak_amd import multigpu
+coresident = int(sys.argv[1])
+eng = multigpu.HipEngine(0)
+rng = np.random.default_rng(3)
+G = rng.normal(size=(128, 128))
+blocks = {"well": G @ G.T + 128 * np.eye(128),
+          "ill": (G * np.logspace(0, -5, 128)) @ (G * np.logspace(0, -5, 128)).T + 1e-9 * np.eye(128)}
+digest = hashlib.sha256()
+for name, A in blocks.items():
+    Ain = np.tril(A) + np.triu(rng.normal(size=(128, 128)) * 1e3, 1)      # the kernel reads the lower triangle only
+    blk = eng.from_numpy(np.asfortranarray(Ain).T.ravel().copy())
     inv = eng.empty(2 * 128 * 128)
     info = eng.zeros(4, dtype=torch.int32); info.fill_(0x7fffffff)
-    eng.factor_panel_co(big, 384, 384, 256, 128, inv, info, coresident)
+    eng.factor_panel_co(blk, 128, 128, 0, 128, inv, info, coresident)
     torch.cuda.synchronize()
-    assert int(info.cpu()[0]) == 256 + 70 + 1
-    test_block_kernel_directly.outs = getattr(test_block_kernel_directly, "outs", {})
-    test_block_kernel_directly.outs[coresident] = outs
-    if len(test_block_kernel_directly.outs) == 2:                    # the two builds do the same arithmetic
-        for name in blocks:
-            for a, b in zip(test_block_kernel_directly.outs[0][name], test_block_kernel_directly.outs[1][name]):
-                assert np.array_equal(a, b)
+    out = blk.cpu().numpy().reshape(128, 128).T
+    L = np.tril(out)
+    iv = inv.cpu().numpy()
+    Li, LiT = iv[:128 * 128].reshape(128, 128).T, iv[128 * 128:].reshape(128, 128).T
+    Lref = np.linalg.cholesky(A)
+    assert int(info.cpu()[0]) == 0x7fffffff
+    assert np.abs(L - Lref).max() <= (1e-12 if name == "well" else 1e-7) * np.abs(Lref).max(), name
+    assert np.abs(L @ L.T - A).max() <= 1e-13 * np.abs(A).max(), name
+    assert np.abs(Li @ L - np.eye(128)).max() <= (1e-12 if name == "well" else 1e-6), name
+    assert np.array_equal(LiT, Li.T)
+    tiles = np.kron(np.eye(8), np.ones((16, 16))) > 0                       # the diagonal 16 x 16 tiles
+    assert np.array_equal(np.triu(out, 1)[tiles], np.zeros(tiles.sum()))    # ... come back cleanly lower
+    above = np.triu(np.ones((128, 128)), 1) > 0
+    assert np.array_equal(out[above & ~tiles], Ain[above & ~tiles])         # the tiles above them are not touched
+    digest.update(L.tobytes()); digest.update(Li.tobytes())
+# not positive definite from column 70 (0-based) of a block that starts at global column 256
+A = blocks["well"].copy()
+A[70, 70] = -1.0
+big = eng.zeros(384 * 128)                                       # block column [256, 384) of a 384-row matrix
+big.view(128, 384)[:, 256:] = eng.from_numpy(np.asfortranarray(A).T.ravel().copy()).view(128, 128)
+inv = eng.empty(2 * 128 * 128)
+info = eng.zeros(4, dtype=torch.int32); info.fill_(0x7fffffff)
+eng.factor_panel_co(big, 384, 384, 256, 128, inv, info, coresident)
+torch.cuda.synchronize()
+assert int(info.cpu()[0]) == 256 + 70 + 1, int(info.cpu()[0])
+print(json.dumps({"digest": digest.hexdigest()}))
+'''
+
+
+def test_block_kernel_directly():
+    """gpak_potrf128_f64 (8 waves) and gpak_potrf128_co_f64 (4 waves, 80 VGPRs) on single 128 x 128 blocks through the
+    device-level C-ABI: L, L^-1 and L^-T against NumPy for a well- and an ill-conditioned block, junk in the upper
+    triangle ignored, the first non-positive pivot reported (1-based global column), and both builds bit-identical.
+    (Subprocesses: torch holds the device buffers here, and its HIP runtime must come up before the library's.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for coresident in (0, 1):
+        r = subprocess.run([sys.executable, "-c", _BLOCK_KERNEL_SCRIPT, str(coresident)], cwd=root,
+                           env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        digests.append(json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])["digest"])
+    assert digests[0] == digests[1]
 
 
 @pytest.mark.parametrize("d", [3, 4])
