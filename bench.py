@@ -329,6 +329,136 @@ def run_single(args):
     return out
 
 
+def run_inproc(args):
+    """ONE process driving all N GPUs (gpak_create_multi: one host thread per device, RCCL communicators made by one
+    ncclCommInitAll, or the in-process peer-copy transport).  Same step, same timing contract."""
+    from gp_ss_ak_amd import gpak, synth
+    P = args.gpus
+    devs = [int(v) for v in os.environ["GPAK_MULTI_DEVICES"].split(",")] if os.environ.get("GPAK_MULTI_DEVICES") else list(range(P))
+    if len(devs) != P:
+        raise SystemExit(f"GPAK_MULTI_DEVICES names {len(devs)} devices, --gpus is {P}")
+    g = gpak.Gpak(devices=devs)
+    mode = gpak.DIST_DIRECT if args.dist == "direct" else gpak.DIST_EXPANSION
+
+    def one_size(N, steps, warmup):
+        X, y = synth.drillholes(N)
+        g.set_train(X, y)
+        wall, nlz, _, _ = _timed_steps(g, mode, steps, warmup)
+        per_rank = []
+        for r in range(P):
+            st = g.rank_stats(r)
+            per_rank.append({k: round(v, 3) for k, v in st.items()
+                             if k.endswith("_ms") or k in ("bulk_flops", "bytes_broadcast", "rank")})
+        Np = g.timing()["n_padded"]
+        flops = Np ** 3 / 3.0
+        per_step = wall / steps
+        bulk_tf = [p["bulk_flops"] / (p["bulk_ms"] * 1e-3) / 1e12 if p["bulk_ms"] > 0 else None for p in per_rank]
+        return {"N": N, "steps_per_s": steps / wall, "ms_per_step": per_step * 1e3, "nlz": nlz,
+                "whole_step_tflops_per_gpu": flops / per_step / 1e12 / P,
+                "whole_step_frac_of_mfma_peak": flops / per_step / 1e12 / P / PEAK_F64_MFMA_TFLOPS,
+                "bulk_update_tflops_per_rank": bulk_tf, "bytes_broadcast_per_step": per_rank[0]["bytes_broadcast"],
+                "phases_ms_per_rank_last_step": per_rank, "stream_flags": g.rank_stats(0)["flags"]}
+
+    main = one_size(args.n, args.steps, args.warmup)
+    transport = g.transport()
+    tfs = [v for v in main["bulk_update_tflops_per_rank"] if v]
+    out = {
+        "metric": f"GP train step/sec (Gram+Cholesky+logML) at N={args.n} fp64",
+        "value": main["steps_per_s"], "unit": "steps/s", "n_gpus": P, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"N={args.n} fp64 ExpAns+Bias Gram + block-column-cyclic Cholesky + solves + logML, C++ "
+                               f"schedule (csrc/dist.hip) driven by ONE process with a host thread per GPU "
+                               f"(gpak_create_multi), sub-panel broadcast over {transport}",
+                   "N": args.n, "dist_mode": args.dist, "nb_outer": 512, "parallelism": f"block-column-cyclic x{P}",
+                   "host": "one process, one thread per GPU", "transport": transport, "devices": devs},
+        "nlz": main["nlz"],
+        "roofline": {"kernel": "gpak_gemm_nt_f64_rs<4,2,true> (bulk trailing update of the owned block columns)",
+                     "bound": "mfma", "achieved": min(tfs) if tfs else None, "peak": PEAK_F64_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": (min(tfs) / PEAK_F64_MFMA_TFLOPS) if tfs else None, "traffic": None,
+                     "traffic_note": "no PMC pass exists for a multi-GPU run (the builder's boxes have one GPU)",
+                     "note": "slowest rank's bulk launches of the LAST step: algorithmic flops / summed launch durations (hipEvents)"},
+        "bytes_broadcast_per_step": main["bytes_broadcast_per_step"],
+        "phases_ms_per_rank": main["phases_ms_per_rank_last_step"],
+        "whole_step_frac_of_mfma_peak_per_gpu": main["whole_step_frac_of_mfma_peak"],
+        "stream_flags": main["stream_flags"],
+    }
+    if args.n != 65536 and not args.no_n65536:
+        out["n65536"] = one_size(65536, max(1, min(args.steps, 3)), 1)
+    g.close()
+    return out
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_child(cmd, env, limit_s):
+    """Runs one child (its own process group) to completion or to `limit_s`; returns (rc or None on time-out, last JSON
+    object printed on stdout or None, tail of stderr)."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, cwd=ROOT)
+    try:
+        so, se = p.communicate(timeout=limit_s)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)     # exactly the group this call started
+        except ProcessLookupError:
+            pass
+        so, se = p.communicate()
+        rc = None
+    line = None
+    for ln in so.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                line = json.loads(ln)
+            except ValueError:
+                pass
+    return rc, line, se.decode(errors="replace")[-1500:]
+
+
+def launch_multi(args, argv):
+    """`python3 bench.py --gpus N` typed as is (no launcher, WORLD_SIZE unset): this process has not touched a GPU; it
+    starts the run as a CHILD and relays the child's JSON line.  Order: (1) one process per GPU under
+    torch.distributed.run (the contract's shape: RCCL inside the library, gloo control plane); (2) if that fails or
+    does not finish: ONE process with a host thread per GPU (gpak_create_multi).  Whatever ran is named in the line
+    (`launcher`, `config.host`, `config.transport`); attempts that failed are listed with their reason."""
+    N = args.gpus
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit = float(os.environ.get("GPAK_BENCH_CHILD_TIMEOUT_S", "420"))
+    attempts = []
+    order = [m for m in os.environ.get("GPAK_BENCH_MULTI_ORDER", "torchrun,inproc").split(",") if m]
+    t_all = time.perf_counter()
+    for how in order:
+        if how == "torchrun":
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={N}", "--master-addr",
+                   "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + argv + ["--no-cpu"]
+        else:
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + argv + ["--inproc", "--no-cpu"]
+        t0 = time.perf_counter()
+        rc, line, err = _run_child(cmd, env, limit)
+        took = time.perf_counter() - t0
+        if rc == 0 and line is not None and line.get("value"):
+            line["launcher"] = {"how": ("bench.py started `python -m torch.distributed.run --nproc-per-node N bench.py` as a child"
+                                        if how == "torchrun" else "bench.py started `bench.py --inproc` (gpak_create_multi) as a child"),
+                                "child_wall_s": took, "failed_attempts": attempts}
+            if not args.no_cpu:
+                line["cpu_baseline"] = cpu_baseline(args.n, args.cpu_n)
+            return line
+        attempts.append({"how": how, "rc": rc, "timed_out": rc is None, "wall_s": took, "stderr_tail": err[-600:]})
+    raise SystemExit("bench.py --gpus %d: every multi-GPU start failed after %.0f s: %s" %
+                     (N, time.perf_counter() - t_all, json.dumps(attempts)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,23 +475,27 @@ def main():
     ap.add_argument("--no-n65536", action="store_true", help="skip the N=65536 sub-run (north_star's scaling size)")
     ap.add_argument("--config2", type=int, default=8192, help="size of the configs[1] sub-run (GPU step and the CPU "
                                                                "reference sequence at full size; 0 = skip)")
-    ap.add_argument("--config3", type=int, default=2, help="L-BFGS iterations of the configs[2] sub-run through the CLI "
+    ap.add_argument("--config3", type=int, default=3, help="L-BFGS iterations of the configs[2] sub-run through the CLI "
                                                             "(N=32768 only; 0 = skip)")
-    ap.add_argument("--profile-tag", default=os.environ.get("GPAK_PROFILE_TAG", "r02"),
+    ap.add_argument("--inproc", action="store_true", help="N > 1: one process, one host thread per GPU (gpak_create_multi)")
+    ap.add_argument("--profile-tag", default=os.environ.get("GPAK_PROFILE_TAG", "r03"),
                     help="profiles/<tag>_pmc_summary_N<N>.json supplies `traffic` and the in-situ clock")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or os.environ.get("GPAK_FORCE_DIST"):
-        # the multi-GPU path: the C++ schedule of csrc/dist.hip over RCCL (GPAK_DIST_IMPL=python selects the
-        # round-1 Python schedule, kept as a test harness)
-        if os.environ.get("GPAK_DIST_IMPL", "cpp") == "python":
-            from gp_ss_ak_amd import multigpu
-            out = multigpu.bench(args)
-        else:
-            from gp_ss_ak_amd import dist as gdist
-            out = gdist.bench(args)
+    if args.inproc and args.gpus > 1:
+        print(json.dumps(run_inproc(args)))
+        return
+    if world > 1 or os.environ.get("GPAK_FORCE_DIST"):
+        # one rank per process under torch.distributed.run: the C++ schedule of csrc/dist.hip over RCCL
+        from gp_ss_ak_amd import dist as gdist
+        out = gdist.bench(args)
         if out is not None:
+            if not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline(args.n, args.cpu_n)
             print(json.dumps(out))
+        return
+    if args.gpus > 1:
+        print(json.dumps(launch_multi(args, sys.argv[1:])))
         return
     out = run_single(args)
     print(json.dumps(out))

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgpak_hip.so")
 
 # every symbol include/gpak.h declares (tests check the header and this list agree)
 SYMBOLS = [
-    "gpak_create", "gpak_create_multi", "gpak_n_gpus", "gpak_destroy", "gpak_last_error", "gpak_global_error", "gpak_set_train",
+    "gpak_create", "gpak_create_multi", "gpak_n_gpus", "gpak_transport", "gpak_destroy", "gpak_last_error", "gpak_global_error", "gpak_set_train",
     "gpak_set_params", "gpak_set_kernel", "gpak_set_option", "gpak_gram", "gpak_compute_k", "gpak_factor",
     "gpak_get_chol_upper", "gpak_failed_column", "gpak_solve_alpha", "gpak_solve_chol", "gpak_nlz",
     "gpak_nlz_terms", "gpak_predict", "gpak_grad", "gpak_grad_hyb", "gpak_timing", "gpak_calibrate",
@@ -48,6 +48,8 @@ def load():
     lib.gpak_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
     lib.gpak_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_int]
     lib.gpak_n_gpus.argtypes = [vp]
+    lib.gpak_transport.argtypes = [vp]
+    lib.gpak_transport.restype = C.c_char_p
     lib.gpak_destroy.argtypes = [vp]
     lib.gpak_destroy.restype = None
     lib.gpak_last_error.argtypes = [vp]

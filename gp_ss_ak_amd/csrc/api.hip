@@ -6,6 +6,7 @@
 #include <cstring>
 #include <limits>
 
+#include "../../include/gpak_dist.h"
 #include "gpak_internal.h"
 
 int gpak_calibrate_impl(gpak_ctx *ctx, double *scratch, size_t scratch_bytes, double *tflops, double *gbs);
@@ -20,7 +21,10 @@ int gpak_multi_set_train(gpak_multi *g, const double *X, const double *y, int N,
 int gpak_multi_set_params(gpak_multi *g, const double *expans, double bias, double sn2, int dist_mode);
 int gpak_multi_nlz(gpak_multi *g, double *nlz, double *quad, double *sumlp, double *logdet);
 int gpak_multi_alpha(gpak_multi *g, double *alpha_host);
-int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f);
+int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f, bool wants_factor);
+int gpak_multi_failed_column(gpak_multi *g);
+const char *gpak_multi_transport(gpak_multi *g);
+int gpak_multi_stats(gpak_multi *g, int r, gpak_dist_stats *out);
 int gpak_multi_predict(gpak_multi *g, const double *Xte, long M, int d, double *mean, double *var);
 int gpak_multi_grad(gpak_multi *g, double *grad10);
 int gpak_multi_timing(gpak_multi *g, gpak_phase_times *out);
@@ -170,7 +174,6 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   hipMalloc(&ctx->dRed, sizeof(double) * 64);
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
   if (const char *pe = getenv("GPAK_FWD_IN_FACTOR")) ctx->fwd_in_factor = atoi(pe) != 0;
-  if (const char *pe = getenv("GPAK_LOOKAHEAD")) ctx->lookahead = atoi(pe) != 0;   // diagnostics: 0 = one stream
   if (const char *pe = getenv("GPAK_LOOKAHEAD")) ctx->lookahead = atoi(pe) != 0;   // diagnostics: 0 = one stream
   const char *nb = getenv("GPAK_NB_OUTER");
   if (nb) ctx->nb_outer = atoi(nb);
@@ -466,6 +469,40 @@ static int ensure_nlz(gpak_ctx *ctx) {
   return GPAK_OK;
 }
 
+// multi.hip: a context of a group takes over the factor its device's rank already holds as packed panels (the
+// result of the group's distributed logLikelihood() for the CURRENT parameters) instead of factoring again:
+// device-to-device copies of N^2/2 doubles where ensure_factor would spend N^3/3 flops.  The context must hold the
+// same training set and parameters (multi.hip's ensure_replica); afterwards it is in the state ensure_nlz leaves.
+int gpak_import_factor(gpak_ctx *ctx, const gpak_dist_factor_view *v) {
+  if (!ctx || !v) return GPAK_EINVAL;
+  if (!ctx->N || v->N != ctx->N || v->Np != ctx->Np || !ctx->have_params) {
+    ctx->err = "gpak_import_factor: the context does not hold the group's training set / parameters";
+    return GPAK_ESTATE;
+  }
+  GPAK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int Np = ctx->Np;
+  const long ld = ctx->ld;
+  for (int b = 0; b < v->nJ; b++) {
+    const int J = b * v->nb, W = std::min(v->nb, Np - J), rows = Np - J;
+    GPAK_HIP(hipMemcpy2DAsync(ctx->dM + J + (size_t)J * ld, sizeof(double) * ld, v->panels[b], sizeof(double) * rows,
+                              sizeof(double) * rows, W, hipMemcpyDeviceToDevice, st));
+    GPAK_HIP(hipMemcpyAsync(ctx->dInv + (size_t)(J / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE, v->invs[b],
+                            sizeof(double) * (W / GPAK_TILE) * 2 * GPAK_TILE * GPAK_TILE, hipMemcpyDeviceToDevice, st));
+  }
+  GPAK_HIP(hipMemcpyAsync(ctx->dAlpha, v->alpha, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
+  GPAK_HIP(hipMemcpyAsync(ctx->dF, v->f, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
+  GPAK_HIP(hipStreamSynchronize(st));
+  ctx->mstate = gpak_ctx::M_L;
+  ctx->z_ok = false;         // dWork does not hold L^-1 (y/sn2)
+  ctx->inv512_ok = false;    // the 512-block inverses were not imported: back substitutions use the 128-blocks
+  ctx->lf_ok = false;        // the fp32 image (GPAK_F32 prediction) is rebuilt from this factor on first use
+  ctx->alpha_ok = true; ctx->nlz_ok = true;
+  ctx->failed_col = 0;
+  ctx->quad = v->quad; ctx->sumlp = v->sumlp; ctx->logdet = v->logdet; ctx->nlz = v->nlz;
+  return GPAK_OK;
+}
+
 // copy an n x m block (ld) of a device matrix to a dense host column-major array
 static int copy_out(gpak_ctx *ctx, const double *dsrc, long ld, int n, int m, double *host) {
   GPAK_HIP(hipMemcpy2DAsync(host, sizeof(double) * n, dsrc, sizeof(double) * ld, sizeof(double) * n, m,
@@ -478,7 +515,7 @@ extern "C" {
 
 int gpak_gram(gpak_ctx *ctx, double *K_host, double *D2_host) {
   if (!ctx) return GPAK_EINVAL;
-  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_gram(c, K_host, D2_host); }));
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_gram(c, K_host, D2_host); }, false));
   GPAK_HIP(hipSetDevice(ctx->device));
   int rc = gpak_ensure_U(ctx);
   if (rc) return rc;
@@ -504,7 +541,7 @@ int gpak_compute_k(gpak_ctx *ctx, const double *X1, int n, const double *X2, int
                    double *D2_host) {
   if (!ctx || !X1 || !X2 || n <= 0 || m <= 0) return GPAK_EINVAL;
   if (ctx->multi)
-    GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_compute_k(c, X1, n, X2, m, d, K_host, D2_host); }));
+    GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_compute_k(c, X1, n, X2, m, d, K_host, D2_host); }, false));
   if (d != 3 && d != 4) { ctx->err = "inputs must have 3 or 4 columns"; return GPAK_ENOTIMPL; }
   if (!ctx->have_params) { ctx->err = "no parameters (gpak_set_params)"; return GPAK_ESTATE; }
   GPAK_HIP(hipSetDevice(ctx->device));
@@ -556,12 +593,20 @@ int gpak_factor(gpak_ctx *ctx) {
   return ensure_factor(ctx);
 }
 
-int gpak_failed_column(const gpak_ctx *ctx) { return ctx ? ctx->failed_col : 0; }
+int gpak_failed_column(const gpak_ctx *ctx) {
+  if (!ctx) return 0;
+  return ctx->multi ? gpak_multi_failed_column(ctx->multi) : ctx->failed_col;
+}
 int gpak_n_gpus(const gpak_ctx *ctx) { return !ctx ? 0 : (ctx->multi ? gpak_multi_n(ctx->multi) : 1); }
+const char *gpak_transport(const gpak_ctx *ctx) { return !ctx ? "" : (ctx->multi ? gpak_multi_transport(ctx->multi) : "none"); }
+int gpak_group_rank_stats(gpak_ctx *ctx, int rank, gpak_dist_stats *out) {
+  if (!ctx || !out || !ctx->multi) return GPAK_EINVAL;
+  return gpak_multi_stats(ctx->multi, rank, out);
+}
 
 int gpak_get_chol_upper(gpak_ctx *ctx, double *R_host) {
   if (!ctx || !R_host) return GPAK_EINVAL;
-  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_get_chol_upper(c, R_host); }));
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_get_chol_upper(c, R_host); }, true));
   int rc = ensure_factor(ctx);
   if (rc) return rc;
   const int N = ctx->N;
@@ -587,7 +632,7 @@ int gpak_solve_alpha(gpak_ctx *ctx, double *alpha_host) {
 
 int gpak_solve_chol(gpak_ctx *ctx, double *X_host, int k) {
   if (!ctx || !X_host || k <= 0) return GPAK_EINVAL;
-  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_solve_chol(c, X_host, k); }));
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_solve_chol(c, X_host, k); }, true));
   int rc = ensure_factor(ctx);
   if (rc) return rc;
   return gpak_solve_chol_impl(ctx, X_host, k);
@@ -678,7 +723,7 @@ int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out) {
 int gpak_calibrate(gpak_ctx *ctx, double *mfma_f64_tflops, double *hbm_write_gbs) {
   if (!ctx || !mfma_f64_tflops || !hbm_write_gbs) return GPAK_EINVAL;
   if (ctx->multi)
-    GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_calibrate(c, mfma_f64_tflops, hbm_write_gbs); }));
+    GPAK_MULTI_ERR(gpak_multi_on_replica0(ctx->multi, [&](gpak_ctx *c) { return gpak_calibrate(c, mfma_f64_tflops, hbm_write_gbs); }, false));
   GPAK_HIP(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)4 << 30;
   double *scratch = nullptr;

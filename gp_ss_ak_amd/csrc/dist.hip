@@ -19,8 +19,11 @@
 // the inverted diagonal blocks, so both triangular solves run locally with no communication.
 #include <dlfcn.h>
 #include <atomic>
-
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -152,6 +155,8 @@ struct Rccl {
   void *lib = nullptr;
   int (*GetUniqueId)(rccl_uid *) = nullptr;
   int (*CommInitRank)(void **, int, rccl_uid, int) = nullptr;
+  int (*CommInitAll)(void **, int, const int *) = nullptr;
+  int (*CommAbort)(void *) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
   int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -170,6 +175,8 @@ struct Rccl {
     GetUniqueId = (int (*)(rccl_uid *))dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (int (*)(void **, int, rccl_uid, int))dlsym(lib, "ncclCommInitRank");
     CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+    CommInitAll = (int (*)(void **, int, const int *))dlsym(lib, "ncclCommInitAll");
+    CommAbort = (int (*)(void *))dlsym(lib, "ncclCommAbort");
     Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclBroadcast");
     AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclAllReduce");
     GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
@@ -257,6 +264,7 @@ struct gpak_dist {
   // results
   bool have_result = false;
   double quad = 0, sumlp = 0, logdet = 0, nlz = 0;
+  int failed_col = 0;                 // 1-based failing column of the last factorisation, min-reduced: the same on every rank
   gpak_dist_stats stats;
 
   // event pools
@@ -416,16 +424,58 @@ int gpak_dist_init_rccl(gpak_dist *h, const char *id) {
   if (h->rccl_state.comm) return GPAK_OK;
   if (!g_rccl.load()) { h->err = g_rccl.err; return GPAK_EHIP; }
   set_device(h);
+  // ncclCommInitRank is a rendezvous of ALL ranks: when one of them never arrives (its start-up failed, its device is
+  // not usable) the others would sit in the bootstrap for ever.  The call therefore runs on a helper thread and this
+  // one waits a bounded time (GPAK_RCCL_INIT_TIMEOUT_S, default 90 s); on a time-out the helper is abandoned (it
+  // holds only the shared state below) and the caller gets an error it can act on -- every host in this repository
+  // then switches ALL ranks to another transport, it never retries RCCL on a subset.
+  struct Shared { std::mutex m; std::condition_variable cv; bool done = false; int rc = -1; void *comm = nullptr; };
+  auto sh = std::make_shared<Shared>();
   rccl_uid u;
   memcpy(u.internal, id, GPAK_DIST_ID_BYTES);
-  int rc = g_rccl.CommInitRank(&h->rccl_state.comm, h->P, u, h->rank);
-  if (rc != 0) {
-    h->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
-    h->rccl_state.comm = nullptr;
+  const int P = h->P, rank = h->rank, dev = h->device;
+  const bool own_dev = h->builtin_engine;
+  std::thread([sh, u, P, rank, dev, own_dev]() {
+    if (own_dev) hipSetDevice(dev);
+    void *c = nullptr;
+    const int rc = g_rccl.CommInitRank(&c, P, u, rank);
+    std::lock_guard<std::mutex> lk(sh->m);
+    sh->rc = rc; sh->comm = c; sh->done = true;
+    sh->cv.notify_all();
+  }).detach();
+  double limit = 90.0;
+  if (const char *e = getenv("GPAK_RCCL_INIT_TIMEOUT_S")) limit = atof(e) > 0 ? atof(e) : limit;
+  std::unique_lock<std::mutex> lk(sh->m);
+  if (!sh->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return sh->done; })) {
+    h->err = "ncclCommInitRank did not return within " + std::to_string((int)limit) + " s (a rank is missing from the rendezvous)";
     return GPAK_EHIP;
   }
+  if (sh->rc != 0) {
+    h->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(sh->rc) : "failed");
+    return GPAK_EHIP;
+  }
+  h->rccl_state.comm = sh->comm;
   return GPAK_OK;
 }
+
+// One process, all devices (multi.hip): the communicators of ALL ranks are made by ONE call from ONE thread
+// (ncclCommInitAll) -- it either yields n communicators or fails as a whole, there is no rendezvous a rank can
+// miss.  comms[r] is then adopted by rank r's handle.
+int gpak_dist_rccl_init_all(int n, const int *devices, void **comms, std::string &err) {
+  if (!g_rccl.load()) { err = g_rccl.err; return GPAK_EHIP; }
+  if (!g_rccl.CommInitAll) { err = "librccl lacks ncclCommInitAll"; return GPAK_EHIP; }
+  const int rc = g_rccl.CommInitAll(comms, n, devices);
+  if (rc != 0) { err = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed"); return GPAK_EHIP; }
+  return GPAK_OK;
+}
+void gpak_dist_rccl_destroy(void *comm) { if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm); }
+int gpak_dist_adopt_rccl(gpak_dist *h, void *comm) {
+  if (!h || !comm) return GPAK_EINVAL;
+  if (!h->builtin_transport) { h->err = "this handle uses a caller-supplied transport"; return GPAK_ESTATE; }
+  h->rccl_state.comm = comm;
+  return GPAK_OK;
+}
+int gpak_dist_failed_column(const gpak_dist *h) { return h ? h->failed_col : 0; }
 
 // A small rehearsal of exactly what the schedule does: a broadcast from every root and an all-reduce on the
 // communication stream while the bulk (CU-masked) stream computes.  Wrong data or an error status on ANY rank
@@ -695,7 +745,9 @@ static int factor(gpak_dist *h, int *failed_col) {
           const int c = h->owned[i];
           const double wt = h->width(c) / GPAK_TILE, mt = (Np - h->start(c)) / GPAK_TILE;
           h->stats.bulk_flops += (wt * mt - wt * (wt - 1) / 2.0) * 2.0 * GPAK_TILE * GPAK_TILE * W;
+          h->stats.bulk_bytes += (wt * mt - wt * (wt - 1) / 2.0) * 2.0 * GPAK_TILE * GPAK_TILE * 8.0;   // C read + written once
         }
+        h->stats.bulk_launches += 1;
       }
       e_bulk_prev = h->sync_event();
       DCHK(E.event_record(E.self, e_bulk_prev, h->s_bulk));
@@ -740,7 +792,7 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   const int N = h->N, Np = h->Np, P = h->P;
   const double t_start = now_ms();
   h->sync_used = 0; h->time_used = 0; h->spans.clear();
-  h->stats.bytes_broadcast = 0; h->stats.bulk_flops = 0;
+  h->stats.bytes_broadcast = 0; h->stats.bulk_flops = 0; h->stats.bulk_bytes = 0; h->stats.bulk_launches = 0;
   h->stats.flags = h->flags;
   size_t tp[6] = {0, 0, 0, 0, 0, 0};
   tp[0] = h->time_event(h->s_bulk);
@@ -764,6 +816,7 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   int bad = 0;
   int rc = factor(h, &bad);
   if (rc) return rc;
+  h->failed_col = bad;
   tp[2] = h->time_event(h->s_bulk);
   if (bad) {
     h->err = "B = I + K/sn2 is not positive definite";
@@ -783,8 +836,10 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   per = (per + 1) / 2 * 2;
   const int i0 = std::min(N, h->rank * per), i1 = std::min(N, (h->rank + 1) * per);
   DCHK(E.zero(E.self, h->s_bulk, h->f, sizeof(double) * Np));
+  const size_t tk0 = h->time_event(h->s_bulk);
   if (i1 > i0)
     DCHK(E.kmatvec(h->s_bulk, h->u, h->cap, N, i0, i1, h->alpha, h->expans, h->bias, h->mode, h->scratch, h->f));
+  const size_t tk1 = h->time_event(h->s_bulk);
   DCHK(hop_in(h));
   DCHK(T.allreduce_sum(T.self, h->s_comm, h->f, (size_t)Np));
   DCHK(hop_out(h));
@@ -810,6 +865,7 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   S.step_ms = now_ms() - t_start;
   auto el = [&](size_t a, size_t b) { double ms = 0; E.event_elapsed_ms(E.self, h->ev_time[a], h->ev_time[b], &ms); return ms; };
   S.fill_ms = el(tp[0], tp[1]); S.factor_ms = el(tp[1], tp[2]); S.solve_ms = el(tp[2], tp[3]); S.nlz_ms = el(tp[3], tp[4]);
+  S.kmatvec_ms = el(tk0, tk1);
   S.bulk_ms = S.chain_ms = S.comm_ms = 0;
   if (h->profile) {
     DCHK(E.stream_sync(E.self, h->s_panel));
@@ -895,3 +951,15 @@ int gpak_dist_get_stats(gpak_dist *h, gpak_dist_stats *out) {
 }
 
 }  // extern "C"
+
+// internal (gpak_internal.h): what multi.hip needs to hand this rank's copy of the factor to a single-GPU context
+int gpak_dist_factor_view_get(gpak_dist *h, gpak_dist_factor_view *out) {
+  if (!h || !out) return GPAK_EINVAL;
+  if (!h->have_result) { h->err = "no current factor (gpak_dist_nlz has not succeeded for these parameters)"; return GPAK_ESTATE; }
+  out->N = h->N; out->Np = h->Np; out->nb = h->nb; out->nJ = h->nJ;
+  out->panels = h->panels.data(); out->invs = h->invs.data();
+  out->alpha = h->alpha; out->f = h->f;
+  out->quad = h->quad; out->sumlp = h->sumlp; out->logdet = h->logdet; out->nlz = h->nlz;
+  return GPAK_OK;
+}
+double gpak_dist_grad_ms(const gpak_dist *h) { return h ? h->grad_ms : 0.0; }

@@ -211,7 +211,13 @@ __device__ __forceinline__ double gpak_exp_neg_tab(double s, const double *tab) 
 }
 // sqrt(d) for the argument of exp(-sqrt(d)): v_rsq_f64 + two Goldschmidt steps, no final residual correction (an ulp
 // or two in s is an absolute 1e-16 * s in the exponent)
+// The argument is clamped at 640000 (s = 800: exp(-s) has flushed to 0 long before, at s = 745) so that the table
+// exponent of gpak_exp_neg_tab -- rint(-s 32/ln2) read from 32 mantissa bits -- can never wrap (it did for s > 4.65e7
+// and gave +inf), and an overflowed D2 = +inf yields K = bias instead of NaN.  Only the HIGH dword is replaced (one
+// v_cmp_gt_f64 + one v_cndmask_b32; whatever the low dword holds, the result still flushes); a NaN coordinate fails
+// the comparison and stays NaN.
 __device__ __forceinline__ double gpak_sqrt_nonneg_fast(double d) {
+  d = __hiloint2double(d > 640000.0 ? 0x41238800 : __double2hiint(d), __double2loint(d));   // 640000.0 = 0x4123880000000000
   const double y = __builtin_amdgcn_rsq(d);
   double g = d * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
@@ -305,6 +311,20 @@ void gpak_launch_axpy(hipStream_t st, int n, double a, const double *x, double *
 
 // ---- predict.hip ------------------------------------------------------------------------
 void gpak_predict_release(gpak_ctx *ctx);
+
+// ---- the distributed factor as one rank holds it (dist.hip), handed to a single-GPU context of the SAME device
+// (multi.hip: group prediction and solve_chol reuse the factor instead of factoring a replica again) ----
+struct gpak_dist;
+struct gpak_dist_factor_view {
+  int N, Np, nb, nJ;
+  const double *const *panels;   // per block column: packed W x (Np - J), leading dimension Np - J, rows from the diagonal block down
+  const double *const *invs;     // per block column: W/128 x 2 x 128 x 128 inverted diagonal blocks (inverse, inverse transposed)
+  const double *alpha, *f;       // Np each (device)
+  double quad, sumlp, logdet, nlz;
+};
+int gpak_dist_factor_view_get(gpak_dist *h, gpak_dist_factor_view *out);
+double gpak_dist_grad_ms(const gpak_dist *h);
+int gpak_import_factor(gpak_ctx *ctx, const gpak_dist_factor_view *v);
 
 // ---- grad.hip ---------------------------------------------------------------------------
 void gpak_grad_release(gpak_ctx *ctx);

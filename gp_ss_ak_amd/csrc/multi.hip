@@ -24,6 +24,10 @@
 
 int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, double *var, const double *pool_sum,
                       long pool_M);
+// dist.hip (not part of the C-ABI): all communicators of one process made by ONE ncclCommInitAll call
+extern "C" int gpak_dist_rccl_init_all(int n, const int *devices, void **comms, std::string &err);
+extern "C" void gpak_dist_rccl_destroy(void *comm);
+extern "C" int gpak_dist_adopt_rccl(gpak_dist *h, void *comm);
 
 namespace {
 
@@ -164,17 +168,32 @@ struct gpak_multi {
   int dist_mode = GPAK_DIST_DIRECT;
   std::vector<char> replica_train_ok, replica_params_ok;
   int nb = 512;
-  std::string err;
+  std::string err;                   // written by the caller's thread only, after run(): see fail()
+  std::vector<std::string> rank_err; // written by worker r only (slot r), read after run()
   int failed_col = 0;
+  double acc_ms[4] = {0, 0, 0, 0};   // fill / factor / solve / nlz of rank 0, summed over the evaluations since set_train
+  int evaluations = 0;
+  bool factor_current = false;       // the ranks hold the result of the current parameters (set by gpak_multi_nlz)
+  std::vector<char> replica_factor_ok;   // the replica holds the CURRENT factor (imported from the rank's packed panels)
+
+  // worker r reports a failure: its own slot, no shared string
+  int fail(int r, int rc, const std::string &what) { rank_err[r] = what; return rc; }
+  // caller's thread, after run(): the first rank's message becomes the group's
+  void collect_errors() {
+    for (int r = 0; r < P; r++)
+      if (!rank_err[r].empty()) { err = "rank " + std::to_string(r) + ": " + rank_err[r]; break; }
+  }
 
   int run(std::function<int(int)> f) {
     std::unique_lock<std::mutex> lk(m);
     job = std::move(f);
     rc.assign(P, GPAK_OK);
+    for (std::string &e : rank_err) e.clear();
     pending = P;
     job_seq++;
     cv.notify_all();
     cv.wait(lk, [&] { return pending == 0; });
+    collect_errors();
     for (int r = 0; r < P; r++) if (rc[r] != GPAK_OK) return rc[r];
     return GPAK_OK;
   }
@@ -201,20 +220,21 @@ struct gpak_multi {
 static int ensure_replica(gpak_multi *g, int r) {
   if (!g->replicas[r]) {
     int rc = gpak_create(&g->replicas[r], g->devices[r], g->precision);
-    if (rc) { g->err = std::string("replica context: ") + gpak_global_error(); return rc; }
+    if (rc) return g->fail(r, rc, std::string("replica context: ") + gpak_global_error());
   }
   gpak_ctx *c = g->replicas[r];
   if (!g->replica_train_ok[r]) {
     int rc = gpak_set_train(c, g->X.data(), g->y.data(), g->N, g->d);
-    if (rc) { g->err = gpak_last_error(c); return rc; }
+    if (rc) return g->fail(r, rc, gpak_last_error(c));
     g->replica_train_ok[r] = 1;
     g->replica_params_ok[r] = 0;
   }
   if (!g->replica_params_ok[r]) {
-    if (!g->have_params) { g->err = "no parameters (gpak_set_params)"; return GPAK_ESTATE; }
+    if (!g->have_params) return g->fail(r, GPAK_ESTATE, "no parameters (gpak_set_params)");
     int rc = gpak_set_params(c, g->expans, g->bias, g->sn2, g->dist_mode);
-    if (rc) { g->err = gpak_last_error(c); return rc; }
+    if (rc) return g->fail(r, rc, gpak_last_error(c));
     g->replica_params_ok[r] = 1;
+    g->replica_factor_ok[r] = 0;
   }
   return GPAK_OK;
 }
@@ -261,63 +281,102 @@ int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision
     g->devices.push_back(dev);
   }
   g->ranks.assign(n, nullptr); g->replicas.assign(n, nullptr);
-  g->replica_train_ok.assign(n, 0); g->replica_params_ok.assign(n, 0);
+  g->replica_train_ok.assign(n, 0); g->replica_params_ok.assign(n, 0); g->replica_factor_ok.assign(n, 0);
+  g->rank_err.assign(n, std::string());
   g->local_ranks.resize(n);
   g->local.P = n; g->local.stage_d.resize(n); g->local.stage_i.resize(n);
   // RCCL needs one device per rank; several ranks on one device (a test box) use the in-process transport
   const bool distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == (size_t)n;
   const char *tr = getenv("GPAK_MULTI_TRANSPORT");
   g->use_rccl = n > 1 && distinct && !(tr && !strcmp(tr, "local"));
-  char id[GPAK_DIST_ID_BYTES];
-  if (g->use_rccl && gpak_dist_rccl_unique_id(id) != GPAK_OK) g->use_rccl = false;   // librccl missing: in-process transport
+  // Whether RCCL can be used is decided HERE, on the caller's thread, before any rank exists: ncclCommInitAll makes
+  // the communicators of all ranks in one call -- all of them or none -- so no worker can be left waiting in a
+  // rendezvous that a failed peer never joins (ncclCommInitRank per thread had exactly that failure mode).
+  std::vector<void *> comms(n, nullptr);
+  std::string rccl_note;
+  if (g->use_rccl) {
+    std::string why;
+    if (gpak_dist_rccl_init_all(n, g->devices.data(), comms.data(), why) != GPAK_OK) {
+      g->use_rccl = false;
+      rccl_note = " (RCCL start-up failed: " + why + ")";
+      (void)hipGetLastError();
+    }
+  }
   for (int r = 0; r < n; r++) g->threads.emplace_back(&gpak_multi::worker, g, r);
   for (int attempt = 0; attempt < 2; attempt++) {
-    std::atomic<int> rccl_failed{0};
     int rc = g->run([&](int r) {
       if (g->ranks[r]) { gpak_dist_destroy(g->ranks[r]); g->ranks[r] = nullptr; }
       LocalRank &lr = g->local_ranks[r];
       lr.g = &g->local; lr.rank = r; lr.dev = g->devices[r]; lr.seq = 0;
       if (!lr.ready && (hipEventCreateWithFlags(&lr.ready, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&lr.copied, hipEventDisableTiming) != hipSuccess)) return (int)GPAK_EHIP;
+                        hipEventCreateWithFlags(&lr.copied, hipEventDisableTiming) != hipSuccess))
+        return g->fail(r, GPAK_EHIP, "hipEventCreate failed");
+      // the in-process transport pulls with hipMemcpyPeerAsync: map every other device of the group into this one
+      // (without it the copy is staged through the host by the runtime -- correct, but not what xGMI is for)
+      if (attempt == 0)
+        for (int q = 0; q < g->P; q++) {
+          if (g->devices[q] == g->devices[r]) continue;
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, g->devices[r], g->devices[q]) == hipSuccess && can) {
+            hipError_t e = hipDeviceEnablePeerAccess(g->devices[q], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+          }
+          (void)hipGetLastError();
+        }
       gpak_dist_transport t;
       t.self = &lr; t.bcast = lt_bcast; t.allreduce_sum = lt_allreduce_sum; t.allreduce_min_int = lt_allreduce_min_int;
       int v = gpak_dist_create(&g->ranks[r], r, g->P, g->devices[r], nullptr, g->use_rccl ? nullptr : &t);
-      if (v) return v;
-      if (g->use_rccl && gpak_dist_init_rccl(g->ranks[r], id) != GPAK_OK) { rccl_failed++; return (int)GPAK_OK; }
+      if (v) return g->fail(r, v, "gpak_dist_create failed");
+      if (g->use_rccl) {
+        v = gpak_dist_adopt_rccl(g->ranks[r], comms[r]);   // the handle owns the communicator from here on
+        if (v) return g->fail(r, v, gpak_dist_last_error(g->ranks[r]));
+        comms[r] = nullptr;
+      }
       return (int)GPAK_OK;
     });
-    if (rc) { err = "gpak_create_multi: rank creation failed"; gpak_multi_destroy(g); return rc; }
-    if (g->use_rccl && rccl_failed.load()) { g->use_rccl = false; continue; }   // all ranks again, in-process transport
+    if (rc) { err = "gpak_create_multi: rank creation failed: " + g->err; gpak_multi_destroy(g); return rc; }
     if (g->P > 1) {
       // start-up self-check on every rank at once (collectives on the side stream, CU-masked bulk stream)
-      rc = g->run([&](int r) { return gpak_dist_selfcheck(g->ranks[r], nullptr); });
-      if (rc && g->use_rccl) { g->use_rccl = false; continue; }
-      if (rc) { err = std::string("gpak_create_multi: ") + gpak_dist_last_error(g->ranks[0]); gpak_multi_destroy(g); return rc; }
+      rc = g->run([&](int r) {
+        int v = gpak_dist_selfcheck(g->ranks[r], nullptr);
+        return v ? g->fail(r, v, gpak_dist_last_error(g->ranks[r])) : (int)GPAK_OK;
+      });
+      if (rc && g->use_rccl) { g->use_rccl = false; rccl_note = " (RCCL self-check failed: " + g->err + ")"; continue; }   // all ranks again
+      if (rc) { err = std::string("gpak_create_multi: ") + g->err; gpak_multi_destroy(g); return rc; }
     }
     break;
   }
-  g->transport_name = g->use_rccl ? "rccl" : (n > 1 ? "in-process peer copies" : "none");
+  for (void *c : comms) gpak_dist_rccl_destroy(c);   // communicators nobody adopted (the fall-back path)
+  g->transport_name = g->use_rccl ? "rccl" : (n > 1 ? "in-process peer copies" + rccl_note : "none");
   *out = g;
   return GPAK_OK;
 }
 
 const char *gpak_multi_error(gpak_multi *g) { return g->err.c_str(); }
 const char *gpak_multi_transport(gpak_multi *g) { return g->transport_name.c_str(); }
+int gpak_multi_failed_column(gpak_multi *g) { return g->failed_col; }
 
 int gpak_multi_set_train(gpak_multi *g, const double *X, const double *y, int N, int d) {
   if (d != 3) { g->err = "a multi-GPU context handles 3-D inputs"; return GPAK_ENOTIMPL; }
   g->X.assign(X, X + (size_t)N * d); g->y.assign(y, y + N);
   g->N = N; g->d = d;
   std::fill(g->replica_train_ok.begin(), g->replica_train_ok.end(), 0);
-  int rc = g->run([&](int r) { return gpak_dist_set_train(g->ranks[r], g->X.data(), g->y.data(), N, d, g->nb); });
-  if (rc) g->err = gpak_dist_last_error(g->ranks[0]);
-  return rc;
+  std::fill(g->replica_factor_ok.begin(), g->replica_factor_ok.end(), 0);
+  g->acc_ms[0] = g->acc_ms[1] = g->acc_ms[2] = g->acc_ms[3] = 0;
+  g->evaluations = 0;
+  g->failed_col = 0;
+  return g->run([&](int r) {
+    int v = gpak_dist_set_train(g->ranks[r], g->X.data(), g->y.data(), N, d, g->nb);
+    return v ? g->fail(r, v, gpak_dist_last_error(g->ranks[r])) : (int)GPAK_OK;
+  });
 }
 
 int gpak_multi_set_params(gpak_multi *g, const double *expans, double bias, double sn2, int dist_mode) {
   memcpy(g->expans, expans, sizeof(double) * 8);
   g->bias = bias; g->sn2 = sn2; g->dist_mode = dist_mode; g->have_params = true;
   std::fill(g->replica_params_ok.begin(), g->replica_params_ok.end(), 0);
+  std::fill(g->replica_factor_ok.begin(), g->replica_factor_ok.end(), 0);
+  g->factor_current = false;
   for (int r = 0; r < g->P; r++) {
     int rc = gpak_dist_set_params(g->ranks[r], expans, bias, sn2, dist_mode);
     if (rc) { g->err = gpak_dist_last_error(g->ranks[r]); return rc; }
@@ -328,9 +387,23 @@ int gpak_multi_set_params(gpak_multi *g, const double *expans, double bias, doub
 int gpak_multi_nlz(gpak_multi *g, double *nlz, double *quad, double *sumlp, double *logdet) {
   if (!g->N) { g->err = "no training set (gpak_set_train)"; return GPAK_ESTATE; }
   std::vector<double> v(g->P, std::numeric_limits<double>::quiet_NaN());
-  int rc = g->run([&](int r) { return gpak_dist_nlz(g->ranks[r], &v[r]); });
+  const bool fresh = !g->factor_current;
+  int rc = g->run([&](int r) {
+    int s = gpak_dist_nlz(g->ranks[r], &v[r]);
+    return s ? g->fail(r, s, gpak_dist_last_error(g->ranks[r])) : (int)GPAK_OK;
+  });
   if (nlz) *nlz = v[0];
-  if (rc) { g->err = gpak_dist_last_error(g->ranks[0]); return rc; }
+  g->failed_col = gpak_dist_failed_column(g->ranks[0]);   // min-reduced inside factor(): the same on every rank
+  if (fresh) {   // a new evaluation (not a cached result): rank 0's phase times join the accumulated totals
+    gpak_dist_stats st;
+    if (gpak_dist_get_stats(g->ranks[0], &st) == GPAK_OK) {
+      g->acc_ms[0] += st.fill_ms; g->acc_ms[1] += st.factor_ms;
+      if (rc == GPAK_OK) { g->acc_ms[2] += st.solve_ms; g->acc_ms[3] += st.nlz_ms; }
+      g->evaluations++;
+    }
+  }
+  if (rc) return rc;
+  g->factor_current = true;
   if (quad || sumlp || logdet) rc = gpak_dist_nlz_terms(g->ranks[0], quad, sumlp, logdet);
   return rc;
 }
@@ -340,39 +413,75 @@ int gpak_multi_alpha(gpak_multi *g, double *alpha_host) {
   int rc = gpak_multi_nlz(g, &v, nullptr, nullptr, nullptr);
   if (rc) return rc;
   if (!alpha_host) return GPAK_OK;
-  rc = g->run([&](int r) { return r == 0 ? gpak_dist_get_alpha(g->ranks[0], alpha_host) : (int)GPAK_OK; });
-  if (rc) g->err = gpak_dist_last_error(g->ranks[0]);
-  return rc;
+  return g->run([&](int r) {
+    if (r != 0) return (int)GPAK_OK;
+    int s = gpak_dist_get_alpha(g->ranks[0], alpha_host);
+    return s ? g->fail(0, s, gpak_dist_last_error(g->ranks[0])) : (int)GPAK_OK;
+  });
 }
 
 // GP_utils::GradLL on the group: B^-1 by row blocks over the ranks (gpak_dist_grad)
 int gpak_multi_grad(gpak_multi *g, double *grad10) {
+  double v;
+  int rc = gpak_multi_nlz(g, &v, nullptr, nullptr, nullptr);   // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
+  if (rc) return rc;
   std::vector<std::vector<double>> gs(g->P, std::vector<double>(10, 0.0));
-  int rc = g->run([&](int r) { return gpak_dist_grad(g->ranks[r], gs[r].data()); });
-  if (rc) { g->err = gpak_dist_last_error(g->ranks[0]); return rc; }
+  rc = g->run([&](int r) {
+    int s = gpak_dist_grad(g->ranks[r], gs[r].data());
+    return s ? g->fail(r, s, gpak_dist_last_error(g->ranks[r])) : (int)GPAK_OK;
+  });
+  if (rc) return rc;
   memcpy(grad10, gs[0].data(), sizeof(double) * 10);
   return GPAK_OK;
 }
 
-int gpak_multi_stats(gpak_multi *g, int r, gpak_dist_stats *out) { return gpak_dist_get_stats(g->ranks[r], out); }
-
-// the calls that are not distributed run on the replica of device 0 (on its own thread: a HIP context per thread)
-int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f) {
-  int rc = g->run([&](int r) {
-    if (r != 0) return (int)GPAK_OK;
-    int v = ensure_replica(g, 0);
-    if (v) return v;
-    v = f(g->replicas[0]);
-    if (v) g->err = gpak_last_error(g->replicas[0]);
-    return v;
-  });
-  return rc;
+int gpak_multi_stats(gpak_multi *g, int r, gpak_dist_stats *out) {
+  if (r < 0 || r >= g->P) return GPAK_EINVAL;
+  return gpak_dist_get_stats(g->ranks[r], out);
 }
 
-// GP_utils::posteriorMeanVar with the test points sharded over the devices; every device factors its own replica
-// (N^3/3 each, concurrently) and predicts a contiguous slice with the pooled mean of ALL test points
+// bring the replica of rank r up to the group's CURRENT factor without factoring again: every rank keeps the whole
+// factor as packed panels (+ the inverted diagonal blocks, alpha and f), on the replica's own device
+static int replica_with_factor(gpak_multi *g, int r) {
+  int v = ensure_replica(g, r);
+  if (v) return v;
+  if (g->replica_factor_ok[r]) return GPAK_OK;
+  gpak_dist_factor_view view;
+  v = gpak_dist_factor_view_get(g->ranks[r], &view);
+  if (v) return g->fail(r, v, gpak_dist_last_error(g->ranks[r]));
+  v = gpak_import_factor(g->replicas[r], &view);
+  if (v) return g->fail(r, v, gpak_last_error(g->replicas[r]));
+  g->replica_factor_ok[r] = 1;
+  return GPAK_OK;
+}
+
+// the calls that are not distributed run on the replica of device 0 (on its own thread: a HIP context per thread);
+// calls that only READ the factor (solve_chol, the factor copy) get it imported, the others rebuild what they need
+int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f, bool wants_factor) {
+  if (wants_factor) {
+    double v;
+    int rc = gpak_multi_nlz(g, &v, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  return g->run([&](int r) {
+    if (r != 0) return (int)GPAK_OK;
+    int v = wants_factor ? replica_with_factor(g, 0) : ensure_replica(g, 0);
+    if (v) return v;
+    if (!wants_factor) g->replica_factor_ok[0] = 0;   // such a call may overwrite the replica's matrix buffer
+    v = f(g->replicas[0]);
+    return v ? g->fail(0, v, gpak_last_error(g->replicas[0])) : (int)GPAK_OK;
+  });
+}
+
+// GP_utils::posteriorMeanVar with the test points sharded over the devices.  The factor is NOT rebuilt: the group
+// evaluates logLikelihood() once (distributed; _postVar calls it, GP_Utils.cpp:980), then every device assembles its
+// replica's factor from the packed panels it already holds (device-to-device copies, N^2/2 doubles) and predicts a
+// contiguous slice with the pooled mean of ALL test points.
 int gpak_multi_predict(gpak_multi *g, const double *Xte, long M, int d, double *mean, double *var) {
   if (d != g->d) { g->err = "test points must have as many columns as the training set"; return GPAK_EINVAL; }
+  double nlz;
+  int rc = gpak_multi_nlz(g, &nlz, nullptr, nullptr, nullptr);
+  if (rc) return rc;
   double s2[4] = {0, 0, 0, 0};
   for (int k = 0; k < d; k++)
     for (long i = 0; i < M; i++) s2[k] += Xte[i + (size_t)k * M];
@@ -380,34 +489,41 @@ int gpak_multi_predict(gpak_multi *g, const double *Xte, long M, int d, double *
   return g->run([&](int r) {
     const long m0 = std::min(M, r * per), m1 = std::min(M, (r + 1) * per);
     if (m1 <= m0) return (int)GPAK_OK;
-    int v = ensure_replica(g, r);
+    int v = replica_with_factor(g, r);
     if (v) return v;
     gpak_ctx *c = g->replicas[r];
-    double nlz;
-    v = gpak_nlz(c, &nlz);   // _postVar calls logLikelihood() (GP_Utils.cpp:980)
-    if (v) { g->err = gpak_last_error(c); return v; }
     // the slice as its own column-major (m1-m0) x d array
     std::vector<double> xs((size_t)(m1 - m0) * d);
     for (int k = 0; k < d; k++) memcpy(xs.data() + (size_t)k * (m1 - m0), Xte + (size_t)k * M + m0, sizeof(double) * (m1 - m0));
     v = gpak_predict_impl(c, xs.data(), m1 - m0, mean + m0, var ? var + m0 : nullptr, s2, M);
-    if (v) g->err = gpak_last_error(c);
-    return v;
+    return v ? g->fail(r, v, gpak_last_error(c)) : (int)GPAK_OK;
   });
 }
 
-// phase times of a group: the dist rank 0 view of the last step, mapped onto gpak_phase_times
+// phase times of a group: rank 0's view of the last step and the totals since gpak_set_train, mapped onto
+// gpak_phase_times
 int gpak_multi_timing(gpak_multi *g, gpak_phase_times *out) {
   memset(out, 0, sizeof(*out));
   gpak_dist_stats st;
   int rc = gpak_dist_get_stats(g->ranks[0], &st);
   if (rc) return rc;
   out->gram_ms = st.fill_ms; out->factor_ms = st.factor_ms; out->solve_ms = st.solve_ms; out->nlz_ms = st.nlz_ms;
-  out->trailing_ms = st.bulk_ms; out->trailing_flops = st.bulk_flops;
+  out->trailing_ms = st.bulk_ms; out->trailing_flops = st.bulk_flops; out->trailing_bytes = st.bulk_bytes;
+  out->trailing_launches = (int)st.bulk_launches;
+  out->kmatvec_ms = st.kmatvec_ms;
   out->n = st.n; out->n_padded = st.n_padded;
+  // rank 0 fills its own block columns only: their lower tiles
+  for (int b = 0; b < st.n_panels; b += g->P) {
+    const double W = std::min(st.nb, st.n_padded - b * st.nb), rows = st.n_padded - b * st.nb;
+    out->gram_bytes += 8.0 * (W * rows - W * (W - GPAK_TILE) / 2.0);
+  }
+  for (int k = 0; k < 4; k++) out->accumulated_ms[k] = g->acc_ms[k];
+  out->evaluations = g->evaluations;
   if (g->replicas[0]) {
     gpak_phase_times t;
-    if (gpak_timing(g->replicas[0], &t) == GPAK_OK) { out->predict_ms = t.predict_ms; out->grad_ms = t.grad_ms; }
+    if (gpak_timing(g->replicas[0], &t) == GPAK_OK) { out->predict_ms = t.predict_ms; }
   }
+  for (int r = 0; r < g->P; r++) out->grad_ms = std::max(out->grad_ms, gpak_dist_grad_ms(g->ranks[r]));
   return GPAK_OK;
 }
 int gpak_multi_n(gpak_multi *g) { return g->P; }

@@ -164,6 +164,17 @@ class Gpak:
         out["accumulated_ms"] = list(t.accumulated_ms)
         return out
 
+    def transport(self):
+        return self._lib.gpak_transport(self._h).decode()
+
+    def rank_stats(self, rank):
+        """gpak_dist_stats of one rank of a multi-GPU context (last step)."""
+        from . import dist as _dist
+        _dist._load()
+        st = _dist.Stats()
+        self._check(self._lib.gpak_group_rank_stats(self._h, int(rank), C.byref(st)))
+        return {name: getattr(st, name) for name, _ in st._fields_}
+
     def calibrate(self):
         a, b = C.c_double(), C.c_double()
         self._check(self._lib.gpak_calibrate(self._h, C.byref(a), C.byref(b)))

@@ -66,6 +66,9 @@ int  gpak_create(gpak_ctx **out, int device, int precision);
  * the model on devices[0].  3-D inputs, ExpAns(+Bias). */
 int  gpak_create_multi(gpak_ctx **out, int n_gpus, const int *devices, int precision);
 int  gpak_n_gpus(const gpak_ctx *ctx);
+/* how the ranks of a multi-GPU context exchange panels: "rccl", "in-process peer copies" (+ the reason RCCL was
+ * not used, if it was tried), or "none" for one GPU */
+const char *gpak_transport(const gpak_ctx *ctx);
 void gpak_destroy(gpak_ctx *ctx);
 const char *gpak_last_error(const gpak_ctx *ctx);
 /* library-level error text for failures that happen before a ctx exists */

@@ -133,6 +133,8 @@ int gpak_dist_nlz_terms(gpak_dist *h, double *quad, double *sumlp, double *logde
  * communication), the row slabs are all-gathered (P broadcasts, N^2 doubles in total), each rank forms its rows of
  * B^-1 = L^-T L^-1 (N^3/(3P)) and runs the fused pair pass on them; one 16-double all-reduce. */
 int gpak_dist_grad(gpak_dist *h, double *g);
+/* failing column (1-based, the same on every rank) of the last GPAK_ENOTPD, 0 if none: GP_utils::Chol_fail */
+int gpak_dist_failed_column(const gpak_dist *h);
 /* alpha = (K + sn2 I)^-1 y of the last gpak_dist_nlz (replicated), N doubles */
 int gpak_dist_get_alpha(gpak_dist *h, double *alpha_host);
 
@@ -150,8 +152,14 @@ typedef struct {
   double comm_ms;           /* sum of the broadcast calls' durations on the communication stream (incl. waiting
                                for the root)                                                                    */
   double wait_ms;           /* factor_ms - bulk_ms: what the bulk stream spent not updating (chain / comm wait) */
+  double kmatvec_ms;        /* this rank's slice of f = K alpha inside nlz_ms                                   */
+  double bulk_bytes;        /* algorithmic HBM bytes of the bulk launches: every owned lower C tile once each way */
+  double bulk_launches;     /* how many bulk launches that was                                                  */
 } gpak_dist_stats;
 int gpak_dist_get_stats(gpak_dist *h, gpak_dist_stats *out);
+/* the same for rank `rank` of a multi-GPU context made by gpak_create_multi (gpak.h); GPAK_EINVAL for a one-GPU context */
+struct gpak_ctx;
+int gpak_group_rank_stats(struct gpak_ctx *ctx, int rank, gpak_dist_stats *out);
 
 /* vector helpers of the built-in engine (also in the engine table) */
 int gpak_dev_vec_scale(void *stream, int n, const double *in, double s, double *out);

@@ -875,6 +875,103 @@ void orc_grad_ref_d(const double *X, int N, int d, const double *y, const double
 }
 
 
+/* The same sums as orc_grad_ref_d, STREAMED: the caller supplies Q = B^-1 (what GradLL :1202-1206 forms with
+ * solve_chol; here typically LAPACK's) and alpha; K, DD2, QW and R are rebuilt one slab of columns at a time, so
+ * the only N x N array is Q (N = 32768: 8.6 GB instead of the six of orc_grad_ref_d).  Used by
+ * tests/golden/make_golden_grad.py for the gradient golden at the metric's size.  Per slab the distances come
+ * from orc_mahadist(X, X[slab]): in DIRECT mode these are the full call's numbers up to the rounding of the
+ * centring (the pooled mean is per slab); the EXPANSION form's cancellation noise would differ per slab, so the
+ * golden uses DIRECT.  Every formula below is the line of orc_grad_ref_d with the same citation. */
+void orc_grad_ref_q(const double *X, int N, int d, const double *y, const double *Q, size_t ldq,
+                    const double *alpha, const double *expans, double bias, double sn2, int mode, double *g) {
+  enum { W = 256 };
+  double par[7];
+  pack_paramker(expans, par);
+  double var2 = expans[6] * expans[6];
+  double S[9], Sp[6][9], M[6][9];
+  expans_S_matrices(expans, S, Sp);
+  for (int p = 0; p < 6; p++)
+    for (int t = 0; t < 9; t++) M[p][t] = S[t] * Sp[p][t];            /* S % S_p */
+  /* a_i^(p) = sum(2 (X%X) M_p, 1), XM^(p) = X M_p   (:1192-1194) */
+  double *a = (double *)malloc(sizeof(double) * 6 * (size_t)N);
+  double *XM = (double *)malloc(sizeof(double) * 18 * (size_t)N);
+  for (int p = 0; p < 6; p++)
+    for (int i = 0; i < N; i++) {
+      double s = 0.0;
+      for (int c = 0; c < 3; c++) {
+        double t = 0.0, u = 0.0;
+        for (int k = 0; k < 3; k++) {
+          double x = X[i + (size_t)k * N];
+          t += 2.0 * x * x * M[p][k + 3 * c];
+          u += x * M[p][k + 3 * c];
+        }
+        s += t;
+        XM[((size_t)p * 3 + c) * N + i] = u;
+      }
+      a[(size_t)p * N + i] = s;
+    }
+  double *D = (double *)malloc(sizeof(double) * (size_t)N * W);
+  double *Xs = (double *)malloc(sizeof(double) * (size_t)W * d);
+  double *yhat = (double *)calloc(N, sizeof(double));
+  double gp[6] = {0, 0, 0, 0, 0, 0}, gsig = 0.0, g7 = 0.0, tr = 0.0, sdW = 0.0;
+  for (int j0 = 0; j0 < N; j0 += W) {
+    int w = N - j0 < W ? N - j0 : W;
+    for (int c = 0; c < d; c++)
+      for (int j = 0; j < w; j++) Xs[j + (size_t)c * w] = X[j0 + j + (size_t)c * N];
+    orc_mahadist(X, N, Xs, w, d, par, mode, D);                       /* :925 */
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, ssig = 0, s7 = 0, sw = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s0, s1, s2, s3, s4, s5, ssig, s7, sw)
+    for (int j = 0; j < w; j++) {
+      int gj = j0 + j;
+      const double *q = Q + (size_t)gj * ldq;
+      for (int i = 0; i < N; i++) {
+        double sd = sqrt(D[i + (size_t)j * N]);                       /* :1178 */
+        double kd2 = exp(-1.0 * sd);                                  /* :1176 */
+        double k = var2 * kd2 + bias;                                 /* :881, :366 */
+        double qw = q[i] * (1.0 / sn2) - alpha[i] * alpha[gj];        /* dhyp :1164-1169 */
+        double dk = sd == 0 ? 0.0 : kd2 * (-0.5 / sd);                /* :1179-1183 */
+        if (i == gj) dk = 0.0;                                        /* :1184 */
+        double r = var2 * qw * dk;                                    /* :927, 1185 */
+        sw += 0.5 * q[i] * k;                                         /* dW :1206 (summed: only sum(dW) is used) */
+        ssig += kd2 * qw;                                             /* :1239-1241 */
+        double acc[6];
+        for (int p = 0; p < 6; p++) {
+          const double *xm = XM + (size_t)p * 3 * N;
+          double dot = xm[i] * X[gj] + xm[i + (size_t)N] * X[gj + (size_t)N] +
+                       xm[i + 2 * (size_t)N] * X[gj + 2 * (size_t)N];
+          acc[p] = r * (a[(size_t)p * N + i] + a[(size_t)p * N + gj] - 4.0 * dot);   /* :1195-1197 */
+        }
+        s0 += acc[0]; s1 += acc[1]; s2 += acc[2]; s3 += acc[3]; s4 += acc[4]; s5 += acc[5];
+        if (d == 4) {                                                 /* :1246-1255, weight KD2 as written */
+          const double *x4 = X + (size_t)3 * N;
+          s7 += kd2 * (2.0 * x4[i] * x4[i] + 2.0 * x4[gj] * x4[gj] - 4.0 * x4[i] * x4[gj]);
+        }
+      }
+    }
+    gp[0] += s0; gp[1] += s1; gp[2] += s2; gp[3] += s3; gp[4] += s4; gp[5] += s5;
+    gsig += ssig; g7 += s7; sdW += sw;
+    /* yhat += K[:, slab] alpha[slab]   (mvmK_exact, GP_Utils.cpp:394-397) */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; i++) {
+      double s = 0.0;
+      for (int j = 0; j < w; j++) s += (var2 * exp(-1.0 * sqrt(D[i + (size_t)j * N])) + bias) * alpha[j0 + j];
+      yhat[i] += s;
+    }
+  }
+  for (int i = 0; i < N; i++) tr += Q[i + (size_t)i * ldq] * (1.0 / sn2) - alpha[i] * alpha[i];
+  for (int p = 0; p < 6; p++) g[p] = gp[p];
+  g[6] = 2.0 * gsig * expans[6];                                      /* :1241-1242 */
+  g[7] = d == 4 ? -2.0 * g7 / N : 0.0;                                /* :1246-1257 */
+  g[8] = tr;                                                          /* Kern_Bias::getGradients :370-377 */
+  double slp = 0.0;
+  for (int i = 0; i < N; i++) {
+    double ymmu = y[i] - yhat[i];
+    slp += (1.0 / sn2) * ymmu * ymmu - 1.0;                           /* :1226-1234 */
+  }
+  g[9] = -1.0 * sdW * (2.0 / sn2) - slp;                              /* updateGlikelihood :846-864 */
+  free(yhat); free(Xs); free(D); free(XM); free(a);
+}
+
 /* GradLL for an arbitrary HybKerns composition (GP_Utils.cpp:1171-1284): the children's
  * getGradients as written -- Kern_ExpAnisotropic (Kernel.cpp:886-1263, recomputes its own
  * MahaDist), Kern_RBF (:491-540) and Kern_Exponential (:644-693), which both work on the D2

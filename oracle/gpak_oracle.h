@@ -18,6 +18,8 @@
 #ifndef GPAK_ORACLE_H
 #define GPAK_ORACLE_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -120,6 +122,11 @@ void orc_grad_ref(const double *X, int N, const double *y, const double *K,
 void orc_grad_ref_d(const double *X, int N, int d, const double *y, const double *K,
                     const double *L, const double *alpha, const double *expans,
                     double bias, double sn2, int mode, double *g);
+
+/* orc_grad_ref_d with Q = B^-1 supplied by the caller (leading dimension ldq) and every other N x N quantity
+ * rebuilt slab by slab: one N x N array instead of six.  For the N = 32768 gradient golden. */
+void orc_grad_ref_q(const double *X, int N, int d, const double *y, const double *Q, size_t ldq,
+                    const double *alpha, const double *expans, double bias, double sn2, int mode, double *g);
 
 /* GradLL for an arbitrary composition; see the .c file.  g: children in order (8 / 2 / 3), bias, sn2 */
 void orc_grad_hyb(const double *X, int N, const double *y, const double *K, const double *L, const double *alpha,

@@ -194,6 +194,22 @@ def grad_ref(X, y, K, L, alpha, expans, bias, sn2, mode=DIST_EXPANSION):
     return g
 
 
+def grad_ref_q(X, y, Q, alpha, expans, bias, sn2, mode=DIST_DIRECT):
+    """orc_grad_ref_q: the as-written gradient from a caller-supplied Q = B^-1 (F-ordered, may be a view with a
+    leading dimension), everything else rebuilt slab by slab."""
+    X = _f(X)
+    N = X.shape[0]
+    assert Q.dtype == np.float64 and Q.flags.f_contiguous or Q.strides[0] == 8
+    ldq = Q.strides[1] // 8
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    e = np.ascontiguousarray(expans, dtype=np.float64)
+    g = np.zeros(10)
+    lib().orc_grad_ref_q(_p(X), C.c_int(N), C.c_int(X.shape[1]), _p(y), _p(Q), C.c_size_t(ldq), _p(alpha), _p(e),
+                         C.c_double(bias), C.c_double(sn2), C.c_int(mode), _p(g))
+    return g
+
+
 def grad_hyb(X, y, K, L, alpha, terms, has_bias, sn2, mode=DIST_EXPANSION):
     X, K, L = _f(X), _f(K), _f(L)
     N = X.shape[0]

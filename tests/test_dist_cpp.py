@@ -250,12 +250,61 @@ def test_bench_distributed_entry_point_over_rccl_one_rank():
 
 
 @pytest.mark.gpu
-def test_bench_falls_back_to_the_python_schedule_when_rccl_cannot_start():
-    """If the library's RCCL start-up fails (here: librccl made unloadable), every rank learns it through the control
-    plane before the first step and the round-1 Python schedule over torch.distributed's NCCL group takes over; the
-    line carries a `fallback` note and the same nlZ."""
+def test_bench_hands_over_to_the_one_process_host_when_rccl_cannot_start():
+    """If the per-process RCCL start-up fails (here: librccl made unloadable), every rank learns it through the control
+    plane before the first step -- no rank is left inside a rendezvous -- and rank 0 runs the SAME C++ schedule from one
+    process (gpak_create_multi); metric, workload and a `fallback` note all say so; same nlZ."""
     d = _bench(1, {"GPAK_FORCE_DIST": "1", "GPAK_DIST_RCCL_WORLD1": "1", "GPAK_RCCL_DISABLE": "1"}, 4096)
     assert "fallback" in d and d["n_gpus"] == 1 and d["value"] > 0
+    assert "fallback host" in d["metric"] and "FALLBACK" in d["config"]["workload"]
+    s = _single(4096)
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
+
+
+def _bench_as_typed(world, size, extra_env, extra_args=()):
+    """exactly `python bench.py --gpus N ...` -- no launcher, WORLD_SIZE unset"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--size", str(size), "--steps", "2",
+                          "--warmup", "1", "--no-n65536", "--no-cpu", *extra_args], env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_as_typed_starts_its_own_launcher():
+    """`python bench.py --gpus 2 --size 4096` as typed: bench.py has not touched a GPU, starts torch.distributed.run as
+    a CHILD and relays the one JSON line (two ranks rehearsed on this box's one GPU, collectives staged through gloo)."""
+    d = _bench_as_typed(2, 4096, {"GPAK_DIST_TRANSPORT": "staged", "GPAK_DIST_DEVICE": "0"})
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["phases_ms_per_rank"]) == 2
+    assert "torch.distributed.run" in d["launcher"]["how"] and d["launcher"]["failed_attempts"] == []
+    assert d["roofline"]["traffic"] is None and d["roofline"]["frac"] > 0
+    s = _single(4096)
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_as_typed_falls_through_to_the_one_process_host():
+    """The first start fails (RCCL refuses two ranks on one device: `invalid usage`), the launcher's second attempt --
+    ONE process, one host thread per rank, in-process peer copies -- produces the line and names the failed attempt."""
+    d = _bench_as_typed(2, 4096, {"GPAK_MULTI_DEVICES": "0,0", "GPAK_DIST_DEVICE": "0", "GPAK_RCCL_INIT_TIMEOUT_S": "40"})
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    how = d["launcher"]["how"] + " " + d.get("fallback", "")
+    assert "gpak_create_multi" in how
+    assert "in-process peer copies" in d["config"]["transport"]
+    s = _single(4096)
+    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_one_process_host_directly():
+    """GPAK_BENCH_MULTI_ORDER=inproc: the launcher goes straight to `bench.py --inproc` (gpak_create_multi)."""
+    d = _bench_as_typed(3, 4096, {"GPAK_MULTI_DEVICES": "0,0,0", "GPAK_BENCH_MULTI_ORDER": "inproc"})
+    assert d["n_gpus"] == 3 and "--inproc" in d["launcher"]["how"] and len(d["phases_ms_per_rank"]) == 3
+    assert d["config"]["host"] == "one process, one thread per GPU" and d["bytes_broadcast_per_step"] > 0
     s = _single(4096)
     assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
 
@@ -306,8 +355,17 @@ def test_multi_context_matches_oracle(orc, ranks, n):
                 assert np.abs(var - vo).max() <= 1e-8 * np.abs(vo).max()
             go = orc.grad_ref(X, y, K, L, alpha, e, synth.DEFAULT_BIAS, sn2, orc.DIST_DIRECT)
             assert np.abs(g.GradLL() - go).max() <= 1e-8 * np.abs(go).max()
+            # prediction, alpha and the gradient all reused the ONE distributed factorisation of these parameters
+            # (the replicas take the factor over from the packed panels their rank holds)
+            assert g.timing()["evaluations"] == k + 1
+            z = np.random.default_rng(k).normal(size=(n, 2))
+            xs = g.solve_chol(z)                                     # solve_chol on the imported factor (rank 0's replica)
+            assert np.abs(L @ (L.T @ xs) - z).max() <= 1e-8 * np.abs(z).max()
+            assert g.timing()["evaluations"] == k + 1
         g.set_params(E, synth.DEFAULT_BIAS, -0.5, gpak.DIST_DIRECT)          # Chol_fail -> NaN on the group too
         assert g.logLikelihood() != g.logLikelihood()
+        assert g.failed_column() == 1                                        # ... with the failing column, as one GPU
+        assert g.transport() == ("none" if ranks == 1 else "in-process peer copies")
     finally:
         g.close()
 

@@ -3,7 +3,8 @@ reference's arithmetic as written (expansion-form distance + IRLS/Brent sequence
 
   configs[1]  N=8192  fp64 Gram + Cholesky           -> oracle bound to OpenBLAS LAPACK + committed LAPACK golden
   configs[2]  N=32768 fp64 (metric size)              -> committed LAPACK golden (tests/golden/golden_N32768.json)
-  configs[2]  gradient of the L-BFGS loop             -> oracle's as-written GradLL up to N=8192
+  configs[2]  gradient of the L-BFGS loop             -> oracle's as-written GradLL up to N=8192, LAPACK-derived golden
+                                                          at N=8192 and N=32768 (tests/golden/golden_grad_N*.json)
   configs[4]  N=32768 fp32 prediction                 -> GPAK_F32 context against the fp64 context, M=65536
 
 The golden JSON files are produced by tests/golden/make_golden_large.py (oracle Gram + SciPy/OpenBLAS
@@ -87,6 +88,33 @@ def test_config3_gradient_vs_oracle(gp, orc, N):
         assert np.abs(g - go).max() <= 1e-8 * np.abs(go).max()
     finally:
         orc.use_builtin()
+        gp.set_train(X[:64], y[:64])
+
+
+@pytest.mark.parametrize("N", [8192, 32768])
+def test_config3_gradient_vs_lapack_golden(gp, N):
+    """configs[2] AT ITS SIZE: the reference-style gradient g[10] of the L-BFGS loop at N=32768 (2N^3/3 inverse + the
+    fused pair pass) against tests/golden/golden_grad_N<N>.json -- B^-1 from an OpenBLAS blocked Cholesky and blocked
+    triangular solves, then the as-written sums (GP_Utils.cpp:1164-1262, Kernel.cpp:886-1263) streamed by
+    orc_grad_ref_q; generated in the build container by tests/golden/make_golden_grad.py, no HIP code involved.
+    Bound: 1e-8 of the largest entry, like the oracle comparison at N <= 8192."""
+    with open(os.path.join(GOLD, f"golden_grad_N{N}.json")) as fh:
+        z = json.load(fh)
+    X, y = synth.drillholes(N)
+    gp.set_train(X, y)
+    try:
+        gp.set_params(np.array(z["expans"]), z["bias"], z["sn2"], gpak.DIST_DIRECT)
+        g = gp.GradLL()
+        go = np.array(z["g"])
+        alpha = gp.solve_alpha()
+        d = np.abs(g - go).max() / np.abs(go).max()
+        print(f"\nN={N} gradient vs LAPACK golden: max |g - g_golden| / max|g_golden| = {d:.2e}; per entry "
+              f"{np.abs(g - go) / np.abs(go).max()}; grad_ms {gp.timing()['grad_ms']:.1f}")
+        assert d <= 1e-8
+        assert g[7] == 0.0 and abs(g[0]) <= 1e-8 * np.abs(go).max()     # 3-D inputs; the AngleX slot cancels to rounding
+        assert abs(np.linalg.norm(alpha) - z["alpha_norm"]) <= 1e-9 * z["alpha_norm"]
+    finally:
+        gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
         gp.set_train(X[:64], y[:64])
 
 

@@ -422,6 +422,38 @@ def test_nan_input_is_not_hidden(gp):
     gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
 
 
+def test_far_apart_points_flush_to_the_bias(gp):
+    """exp(-sqrt(D2)) at the far end of its range: s = 745 is the last value with a non-zero result, and beyond it the
+    covariance must be exactly the bias -- also where the table exponent of the fast exp would have wrapped (s > 4.65e7
+    gave +inf before the argument was clamped) and where D2 itself overflows to +inf (coordinates of 1e200)."""
+    e = E.copy()
+    e[[0, 2, 4]] = 0.0                         # zero angles: sigInv = diag(inverse widths)
+    e[[1, 3, 5]] = 1.0                         # ... = I: D2 is the plain squared distance
+    X, y = synth.drillholes(256)
+    gp.set_train(X, y)
+    gp.set_params(e, BIAS, SN2, gpak.DIST_DIRECT)
+    X1 = np.zeros((1, 3))
+    for far in ([740.0, 745.0, 800.0, 1e5, 5e7], [1e12], [1e200]):   # separate calls: the points are centred on their
+        far = np.array(far)                                           # pooled mean, which must not swamp the small ones
+        X2 = np.zeros((len(far), 3))
+        X2[:, 0] = far
+        K = gp.compute_k(X1, X2)[0]
+        assert np.all(np.isfinite(K))
+        if far[0] == 740.0:
+            assert abs(K[0] - (e[6] ** 2 * np.exp(-740.0) + BIAS)) <= 1e-300 and np.all(K[1:] == BIAS)
+        else:
+            assert np.all(K == BIAS)
+    # the same evaluation inside the fused Gram-matvec: the predictive mean of a point far from every training point is
+    # bias * sum(alpha), its latent variance the prior's
+    alpha = gp.solve_alpha()
+    Xt = np.array([[5e7, 0.0, 0.0], [0.1, 0.2, 0.3], [-3e9, 4e9, 1e8]])
+    mean, var = gp.posteriorMeanVar(Xt)
+    assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var))
+    assert abs(mean[0] - BIAS * alpha.sum()) <= 1e-9 * max(1.0, abs(BIAS * alpha.sum()))
+    assert abs(mean[2] - BIAS * alpha.sum()) <= 1e-9 * max(1.0, abs(BIAS * alpha.sum()))
+    gp.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+
+
 def test_options_and_two_live_contexts(orc):
     """gpak_set_option: every schedule variant gives the same numbers (look-ahead off = the classical order on
     one stream; other outer block sizes); value memoisation skips the rebuild only for bit-identical parameters;
