@@ -278,6 +278,100 @@ __global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f32_rs2(int K, float alph
       }
 }
 
+// ---------------------------------------------------------------------------------------
+// WIDE-accumulation variant (64 x 64 wave tile as gpak_gemm_nt_f32_rs).  The fp32 MFMA accumulates a chunk of 32
+// k-steps (K = 128) from zero; the chunk sums are then added into fp64 totals on the vector ALU, and the epilogue
+// forms alpha * total + beta * C in fp64 and rounds ONCE.  Why: in the forward substitution the terms of a product
+// mostly share a sign, so a running fp32 sum grows ~linearly with K and every one of its K/4 roundings happens at that
+// growing magnitude -- the variance error of the fp32 prediction was measured to grow like K^1.5 with the panel width
+// (two-level 128/512 ladder 6.8e-6 of the largest variance at M = 65536, 128/512/2048: 2.5e-5, .../8192: 7e-5).  With
+// chunks of 128 the fp32 part of a K = 512 product carries (128/512)^1.5 = 1/8 of that.  Cost per chunk and wave: 64
+// conversions + 64 fp64 adds beside 512 MFMAs.
+// ---------------------------------------------------------------------------------------
+template <int RS_D, int OCC>
+__global__ __launch_bounds__(256, OCC) void gpak_gemm_nt_f32_rsw(int K, float alpha, const float *A, long lda,
+                                                                const float *B, long ldb, float beta, float *C,
+                                                                long ldc, int mt, int nt) {
+  int ti, tj;
+  {
+    const int b = blockIdx.x, q = b >> 3;
+    const int slot = q & 63;
+    const int ssel = (q >> 6) * 8 + (b & 7);
+    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
+    const int sj = ssel / SR, si = ssel - sj * SR;
+    if (sj >= SC) return;
+    ti = si * 8 + (slot & 7);
+    tj = sj * 8 + (slot >> 3);
+    if (ti >= mt || tj >= nt) return;
+  }
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w & 1, wc = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const f4 *Ap = reinterpret_cast<const f4 *>(A + (size_t)ti * TM + wr * 64 + 4 * l15 + (size_t)l4 * lda);
+  const f4 *Bp = reinterpret_cast<const f4 *>(B + (size_t)tj * TN + wc * 64 + 4 * l15 + (size_t)l4 * ldb);
+  const size_t sa = (size_t)lda, sb = (size_t)ldb;  // 4 k-columns in 16-B units
+  f4 acc[4][4];
+  double tot[4][4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) tot[mi][ni][r] = 0.0;
+  f4 ra[RS_D], rbv[RS_D];
+  const int n = K / 4;   // k-steps: a multiple of 32 (K is a multiple of 128)
+#pragma unroll
+  for (int s = 0; s < RS_D; s++) {
+    ra[s] = *Ap; rbv[s] = *Bp; Ap += sa; Bp += sb;
+  }
+  for (int c0 = 0; c0 < n; c0 += 32) {
+#pragma unroll
+    for (int s = 0; s < 32; s++) {
+      const int slot = s % RS_D;
+      if (s == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+          for (int ni = 0; ni < 4; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(rbv[slot][ni], ra[slot][mi], (f4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+          for (int ni = 0; ni < 4; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(rbv[slot][ni], ra[slot][mi], acc[mi][ni], 0, 0, 0);
+      }
+      if (c0 + s + RS_D < n) { ra[slot] = *Ap; rbv[slot] = *Bp; Ap += sa; Bp += sb; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) tot[mi][ni][r] += (double)acc[mi][ni][r];
+  }
+  if (A == C) __syncthreads();  // in-place panel product: every wave's operand reads before anybody's stores
+  float *Cg = C + (size_t)ti * TM + wr * 64 + 4 * l15 + ((size_t)tj * TN + wc * 64 + 16 * l4) * ldc;
+  const double da = (double)alpha, db = (double)beta;
+#pragma unroll
+  for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      f4 *p = reinterpret_cast<f4 *>(Cg + (size_t)(4 * r4 + ni) * ldc);
+      double v0 = da * tot[0][ni][r4], v1 = da * tot[1][ni][r4], v2 = da * tot[2][ni][r4], v3 = da * tot[3][ni][r4];
+      if (beta != 0.f) {
+        const f4 c = *p;
+        v0 = fma(db, (double)c.x, v0);
+        v1 = fma(db, (double)c.y, v1);
+        v2 = fma(db, (double)c.z, v2);
+        v3 = fma(db, (double)c.w, v3);
+      }
+      *p = (f4){(float)v0, (float)v1, (float)v2, (float)v3};
+    }
+}
+
 void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha, const float *A, long lda,
                              const float *B, long ldb, float beta, float *C, long ldc) {
   if (mt <= 0 || nt <= 0) return;
@@ -285,7 +379,21 @@ void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha,
   const long nsuper = (long)SR * SC;
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
-  if (use_lds)
+  // Products longer than one chunk take the wide-accumulation kernel (fp32 MFMA chunks of K = 128 summed in fp64):
+  // measured at N = 32768, M = 65536 against the fp64 context, variance error 7.4e-7 of the largest variance instead
+  // of 6.8e-6, for 118 instead of 120.5 TFLOP/s (profiles/r03_f32_accumulation.txt).  A K = 128 product IS one chunk:
+  // the 128 x 64-tile kernel below computes the same sum faster.  GPAK_F32_ACC=plain: the round-2 kernels everywhere.
+  const char *accm = getenv("GPAK_F32_ACC");
+  const bool wide = !(accm && !strcmp(accm, "plain")) && K > 128 && K % 128 == 0;
+  if (wide) {
+    const int v = getenv("GPAK_F32_RSD") ? atoi(getenv("GPAK_F32_RSD")) : 4;
+    if (v == 8)        // one workgroup per CU slot pair: all 512 registers of a SIMD lane for one wave
+      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<8, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+    else if (v == 2)
+      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<2, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+    else
+      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<4, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+  } else if (use_lds)
     hipLaunchKernelGGL(gpak_gemm_nt_f32, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
   else if (!(mt & 1) && (!getenv("GPAK_F32_TILE") || atoi(getenv("GPAK_F32_TILE")) != 64)) {
     const int mt2 = mt / 2, SR2 = (mt2 + 7) / 8;
@@ -376,15 +484,17 @@ __global__ __launch_bounds__(256) void gpak_rowsumsq_part_f32(const float *__res
   if (t >= rows) return;
   const int c0 = blockIdx.y * cols_per_split;
   const int c1 = min(cols, c0 + cols_per_split);
-  double s = 0.0;
-  float blk = 0.f;
-  int n = 0;
-  for (int c = c0; c < c1; c++) {
-    const float a = V[t + (size_t)c * ldv];
-    blk = fmaf(a, a, blk);
-    if (++n == 64) { s += blk; blk = 0.f; n = 0; }  // fp32 partials of 64 terms, fp64 across them
+  // the squares and their sum in fp64 (the kernel streams fp32 at the HBM rate; 2e9 fp64 FMAs per batch are free):
+  // what is subtracted from kD is then exactly the sum of the stored fp32 values' squares
+  double s = 0.0, s2 = 0.0;
+  int c = c0;
+  for (; c + 1 < c1; c += 2) {
+    const double a = (double)V[t + (size_t)c * ldv], b = (double)V[t + (size_t)(c + 1) * ldv];
+    s = fma(a, a, s);
+    s2 = fma(b, b, s2);
   }
-  part[(size_t)blockIdx.y * part_ld + t] = s + blk;
+  if (c < c1) { const double a = (double)V[t + (size_t)c * ldv]; s = fma(a, a, s); }
+  part[(size_t)blockIdx.y * part_ld + t] = s + s2;
 }
 void gpak_launch_rowsumsq_f32(hipStream_t st, const float *V, long ldv, int rows, int cols, int splits,
                               double *part, int part_ld) {

@@ -126,27 +126,49 @@ static int ensure_f32_factor(gpak_ctx *ctx) {
   return GPAK_OK;
 }
 
-// the same two-level forward substitution in fp32 (v_mfma_f32_16x16x4_f32)
-static void forward_subst_batch_f32(gpak_ctx *ctx, float *Wt, long ldw, int mbp) {
+// The forward substitution in fp32 (v_mfma_f32_16x16x4_f32), MULTI-level: a block of width lv[k] is solved child by
+// child (width lv[k-1]); after each child ONE product of K = lv[k-1] updates the rest of the block.  Wider products
+// move less (each level reads and writes the batch at most 3 times) and keep the MFMA pipe fed longer per launch, but
+// with plain fp32 accumulation they cost accuracy: the terms of a product mostly share a sign, a running fp32 sum
+// grows ~linearly with K and is rounded at that magnitude K/4 times -- measured at N = 32768, M = 65536 against the
+// fp64 context: ladder 128/512 6.8e-6 of the largest variance, 128/512/2048 2.5e-5, 128/512/2048/8192 7e-5
+// (profiles/r03_f32_accumulation.txt).  The products therefore run on gpak_gemm_nt_f32_rsw (fp32 chunks of K = 128
+// summed in fp64, gemm_f32.hip): 7.4e-7 whatever the ladder, which is then chosen for speed alone.
+// GPAK_FS_LEVELS_F32="128,512" restores the two-level scheme (A/B runs).
+static void fs_block_f32(gpak_ctx *ctx, float *Wt, long ldw, int mt, int J0, int W, const std::vector<int> &lv, int k) {
   const int Np = ctx->Np;
   hipStream_t st = ctx->stream;
-  const int mt = mbp / PB;
-  for (int J = 0; J < Np; J += FS_NB) {
-    const int W = std::min(FS_NB, Np - J);
-    for (int j0 = J; j0 < J + W; j0 += PB) {
-      const float *inv = ctx->dInvf + (size_t)(j0 / PB) * 2 * PB * PB;
-      float *Wj = Wt + (size_t)j0 * ldw;
-      gpak_launch_gemm_nt_f32(st, mt, 1, PB, 1.f, Wj, ldw, inv, PB, 0.f, Wj, ldw);
-      const int nin = (J + W - j0 - PB) / PB;
-      if (nin > 0)
-        gpak_launch_gemm_nt_f32(st, mt, nin, PB, -1.f, Wj, ldw, ctx->dLf + (j0 + PB) + (size_t)j0 * Np, Np, 1.f,
-                                Wt + (size_t)(j0 + PB) * ldw, ldw);
-    }
-    const int nrest = (Np - J - W) / PB;
-    if (nrest > 0)
-      gpak_launch_gemm_nt_f32(st, mt, nrest, W, -1.f, Wt + (size_t)J * ldw, ldw, ctx->dLf + (J + W) + (size_t)J * Np,
-                              Np, 1.f, Wt + (size_t)(J + W) * ldw, ldw);
+  if (k == 0) {   // W == 128: product with the explicit inverse of the diagonal block
+    const float *inv = ctx->dInvf + (size_t)(J0 / PB) * 2 * PB * PB;
+    float *Wj = Wt + (size_t)J0 * ldw;
+    gpak_launch_gemm_nt_f32(st, mt, 1, PB, 1.f, Wj, ldw, inv, PB, 0.f, Wj, ldw);
+    return;
   }
+  const int cw = lv[k - 1];
+  for (int j0 = J0; j0 < J0 + W; j0 += cw) {
+    const int w = std::min(cw, J0 + W - j0);
+    fs_block_f32(ctx, Wt, ldw, mt, j0, w, lv, k - 1);
+    const int nrest = (J0 + W - j0 - w) / PB;
+    if (nrest > 0)
+      gpak_launch_gemm_nt_f32(st, mt, nrest, w, -1.f, Wt + (size_t)j0 * ldw, ldw, ctx->dLf + (j0 + w) + (size_t)j0 * Np, Np,
+                              1.f, Wt + (size_t)(j0 + w) * ldw, ldw);
+  }
+}
+static void forward_subst_batch_f32(gpak_ctx *ctx, float *Wt, long ldw, int mbp) {
+  std::vector<int> lv = {PB, 512, 2048, 8192};
+  if (const char *e = getenv("GPAK_FS_LEVELS_F32")) {
+    lv.clear();
+    for (const char *p = e; *p;) {
+      const int v = atoi(p);
+      if (v >= PB && v % PB == 0 && (lv.empty() ? v == PB : v > lv.back() && v % lv.back() == 0)) lv.push_back(v);
+      while (*p && *p != ',') p++;
+      if (*p == ',') p++;
+    }
+    if (lv.empty()) lv = {PB, 512};
+  }
+  lv.push_back(ctx->Np > lv.back() ? ctx->Np : lv.back() + 1);   // the whole matrix is the top block
+  // the top block's width need not be a multiple of its children's: fs_block_f32 clips the last child
+  fs_block_f32(ctx, Wt, ldw, mbp / PB, 0, ctx->Np, lv, (int)lv.size() - 1);
 }
 
 // pool_sum / pool_M: column sums and count of the WHOLE test set when Xte is a slice of it (multi-GPU prediction

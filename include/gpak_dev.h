@@ -4,7 +4,7 @@
  * process with no distribution at all; these entry points are the pieces of
  * GP_utils::ldB2_exact / solve_chol / logLikelihood (GP_Utils.cpp:841-845, 872-915, 1138-1162)
  * that one rank executes on the block columns it owns.  One process per GPU calls them
- * between torch.distributed (RCCL over xGMI) collectives: gp_ss_ak_amd/multigpu.py.
+ * between torch.distributed (RCCL over xGMI) collectives: tests/py_schedule.py (a test harness; the product schedule is csrc/dist.hip).
  *
  * All pointers are DEVICE pointers owned by the caller (e.g. torch tensors); `stream` is a
  * hipStream_t (NULL = the default stream).  Calls only enqueue work; they do not synchronise.

@@ -29,7 +29,8 @@ def main():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(a.port)
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
-    from gp_ss_ak_amd import multigpu, synth
+    import py_schedule as multigpu
+    from gp_ss_ak_amd import synth
     if a.engine == "hip":
         eng = multigpu.HipEngine(0)  # every rank on GPU 0: a schedule test, collectives staged by gloo
     else:

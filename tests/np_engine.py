@@ -1,6 +1,6 @@
 """CPU stand-in for HipEngine, TEST INFRASTRUCTURE ONLY (uses numpy/scipy and the oracle's sigInv).
 
-It lets the world_size>1 gloo tests drive gp_ss_ak_amd.multigpu.DistGP -- the ownership map, the
+It lets the world_size>1 gloo tests drive tests/py_schedule.py's DistGP -- the ownership map, the
 look-ahead schedule, the panel pack/broadcast and the solve collectives -- on a machine without
 a GPU.  It mirrors the semantics of include/gpak_dev.h function by function.
 """

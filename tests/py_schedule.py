@@ -1,4 +1,7 @@
-"""Multi-GPU hot path: block-column-cyclic Cholesky / solves / nlZ, one process per GPU.
+"""TEST INFRASTRUCTURE (moved out of the product package in round 3): the round-1 PYTHON schedule of the multi-GPU hot
+path -- block-column-cyclic Cholesky / solves / nlZ, one process per GPU -- kept as a second, independent implementation
+that tests/test_multigpu.py holds against the oracle, and `HipEngine`, a thin ctypes face of the gpak_dev_* tile
+operations that tests and tools/ use to time single kernels.  The PRODUCT schedule is C++ (csrc/dist.hip).
 
 The reference is a single process; this is the build's own distribution of
 GP_utils::ldB2_exact / solve_chol / logLikelihood (GP_Utils.cpp:841-845, 872-915, 1138-1162):
@@ -41,7 +44,7 @@ class HipEngine:
 
     def __init__(self, device_index):
         torch = _torch()
-        from . import _lib
+        from gp_ss_ak_amd import _lib
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a GPU (there is no CPU fallback)")
         torch.cuda.set_device(device_index)
@@ -581,72 +584,3 @@ class DistGP:
 # ------------------------------------------------------------------------------------------------
 # bench.py --gpus N entry point (launched by torch.distributed.run, one rank per GPU)
 # ------------------------------------------------------------------------------------------------
-def bench(args):
-    torch = _torch()
-    import torch.distributed as dist
-    from . import synth
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); "
-                         f"got WORLD_SIZE={world}")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
-    # GPAK_DIST_BACKEND / GPAK_DIST_DEVICE exist for the tests: they rehearse this exact entry point with
-    # several ranks on the ONE GPU of a test box (gloo stages the collectives; RCCL refuses two ranks per GPU)
-    backend = os.environ.get("GPAK_DIST_BACKEND", "nccl")
-    if "GPAK_DIST_DEVICE" in os.environ:
-        local = int(os.environ["GPAK_DIST_DEVICE"])
-    torch.cuda.set_device(local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    eng = HipEngine(local)
-    N = args.n
-    X, y = synth.drillholes(N)
-    gp = DistGP(eng, X, y, nb=args.nb_outer or 512)
-    mode = 1 if args.dist == "direct" else 0
-    import bench as bench_mod
-
-    def step(i):
-        e, bias, sn2 = bench_mod.params_for_step(i)
-        gp.set_params(e, bias, sn2, mode)
-        return gp.nlz()
-
-    for i in range(args.warmup):
-        step(i)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nlz = None
-    for i in range(args.steps):
-        nlz = step(args.warmup + i)
-    torch.cuda.synchronize()
-    dist.barrier()
-    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=eng.device)
-    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    wall = float(wall.item())
-    out = None
-    if rank == 0:
-        flops = gp.Np ** 3 / 3.0
-        out = {
-            "metric": f"GP train step/sec (Gram+Cholesky+logML) at N={N} fp64",
-            "value": args.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"N={N} fp64 ExpAns+Bias Gram + block-column-cyclic Cholesky + solves + logML, "
-                                   f"panel broadcast over RCCL", "N": N, "dist_mode": args.dist,
-                       "nb_outer": gp.nb, "parallelism": f"block-column-cyclic x{world}"},
-            "nlz": nlz,
-            "roofline": {"kernel": "gpak_gemm_nt_f64_rs (trailing update)", "bound": "mfma",
-                         "achieved": flops / (wall / args.steps) / 1e12 / world,
-                         "peak": bench_mod.PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (wall / args.steps) / 1e12 / world / bench_mod.PEAK_F64_MFMA_TFLOPS,
-                         "traffic": None,
-                         "note": "whole-step N^3/3 flops per GPU over the step time (not a per-kernel figure)"},
-            "bytes_broadcast_per_step": gp.bytes_broadcast,
-        }
-    dist.destroy_process_group()
-    return out

@@ -5,7 +5,7 @@ reference's arithmetic as written (expansion-form distance + IRLS/Brent sequence
   configs[2]  N=32768 fp64 (metric size)              -> committed LAPACK golden (tests/golden/golden_N32768.json)
   configs[2]  gradient of the L-BFGS loop             -> oracle's as-written GradLL up to N=8192, LAPACK-derived golden
                                                           at N=8192 and N=32768 (tests/golden/golden_grad_N*.json)
-  configs[4]  N=32768 fp32 prediction                 -> GPAK_F32 context against the fp64 context, M=65536
+  configs[4]  N=32768 fp32 prediction, M=1e6          -> GPAK_F32 context against the fp64 context on all 1e6 points
 
 The golden JSON files are produced by tests/golden/make_golden_large.py (oracle Gram + SciPy/OpenBLAS
 cho_factor): they are NOT reference output (the reference cannot be built here: parity unpinned), but they come
@@ -186,13 +186,14 @@ def test_lapack_golden_scalars(gp, N):
     gp.set_train(X[:64], y[:64])
 
 
-def test_config5_fp32_prediction_at_32768(gp):
-    """configs[4]: N=32768, fp32 prediction (GPAK_F32 context: fp64 training step, fp32 cross-kernel / forward
-    substitution / variance sums) against the fp64 context on M=65536 block-model points.
-    Tolerance: the latent variance kD - |L^-1 k*|^2/sn2 is a difference of two O(1) numbers computed through an
-    fp32 triangular solve with N=32768 terms per dot product: 1e-3 relative to the largest variance; the mean is
-    fp64 in both contexts (1e-9)."""
-    N, M = 32768, 65536
+def test_config5_fp32_prediction_at_32768_M1e6(gp):
+    """configs[4] AS STATED: N=32768, M=1e6 test points (the 100 x 100 x 100 block model of SURVEY 8(d)), fp32
+    prediction (GPAK_F32 context: fp64 training step; fp32 cross-kernel, forward substitution and variance sums on the
+    fp32 MFMA) against the fp64 context on the same points.
+    Tolerance: north_star's 1e-5 relative on the variance, held at 5e-6 of the largest variance (observed ~1e-6: the
+    substitution's products accumulate fp32 chunks of K=128 in fp64, so what is left is the rounding of the inputs --
+    cross-kernel and factor -- to fp32); the mean is fp64 in both contexts (1e-9)."""
+    N, M = 32768, 1000000
     X, y = synth.drillholes(N)
     Xte = synth.test_points(M)
     g32 = gpak.Gpak(0, gpak.F32)
@@ -202,16 +203,18 @@ def test_config5_fp32_prediction_at_32768(gp):
         g32.set_train(X, y)
         g32.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
         assert g32.logLikelihood() == gp.logLikelihood()          # the training step is the same fp64 code
-        m64, v64 = gp.posteriorMeanVar(Xte)
         m32, v32 = g32.posteriorMeanVar(Xte)
-        t64, t32 = gp.timing()["predict_ms"], g32.timing()["predict_ms"]
+        t32 = g32.timing()["predict_ms"]
+        m64, v64 = gp.posteriorMeanVar(Xte)
+        t64 = gp.timing()["predict_ms"]
         dv = np.abs(v32 - v64)
         print(f"\nconfig5 N={N} M={M}: fp32 vs fp64 variance max rel {dv.max() / v64.max():.2e} "
-              f"(median {np.median(dv) / v64.max():.2e}), mean {rel(m32, m64):.2e}; "
-              f"predict fp64 {t64:.0f} ms, fp32 {t32:.0f} ms")
+              f"(rms {np.sqrt((dv ** 2).mean()) / v64.max():.2e}), mean {rel(m32, m64):.2e}; "
+              f"predict fp64 {t64:.0f} ms ({float(N) * N * M / t64 / 1e9:.1f} TFLOP/s), "
+              f"fp32 {t32:.0f} ms ({float(N) * N * M / t32 / 1e9:.1f} TFLOP/s)")
         assert rel(m32, m64) <= 1e-9
-        assert dv.max() <= 1e-3 * v64.max()
-        assert np.all(v32 >= SN2 * (1 - 1e-6))
+        assert dv.max() <= 5e-6 * v64.max()
+        assert np.all(v32 >= SN2 * (1 - 1e-6)) and np.all(v32 <= (E[6] ** 2 + BIAS + SN2) * (1 + 1e-6))
     finally:
         g32.close()
         gp.set_train(X[:64], y[:64])

@@ -310,7 +310,9 @@ def test_alternative_kernels_give_the_same_step():
 _BLOCK_KERNEL_SCRIPT = r'''
 import hashlib, json, sys
 import numpy as np, torch
-from gp_ss_ak_amd import multigpu
+import os, sys
+sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+import py_schedule as multigpu
 coresident = int(sys.argv[1])
 eng = multigpu.HipEngine(0)
 rng = np.random.default_rng(3)

@@ -1,4 +1,4 @@
-"""The round-1 Python schedule gp_ss_ak_amd.multigpu.DistGP under torch.distributed -- kept as a second, independent
+"""The round-1 Python schedule tests/py_schedule.py DistGP under torch.distributed -- kept as a second, independent
 implementation of the multi-GPU schedule (the product path is the C++ one: tests/test_dist_cpp.py).
 
 CPU (-m "not gpu"): world_size 2 and 3 over gloo with the NumPy stand-in engine -- checks the
@@ -102,46 +102,3 @@ def test_hip_engine_expansion_mode_and_chol_fail(orc):
     assert abs(res[0]["nlz"] - info.nlz) <= 1e-6 * abs(info.nlz)    # expansion mode: cancellation noise
     res = run_world(2, 900, 256, engine="hip", sn2=-0.5)
     assert all(r["nlz"] != r["nlz"] for r in res)
-
-
-@pytest.mark.gpu
-def test_bench_distributed_entry_point_over_rccl():
-    """bench.py --gpus path exactly as the driver launches it (torch.distributed.run, backend nccl = RCCL),
-    with the one rank this box has; the step must agree with the single-context path."""
-    root = os.path.dirname(HERE)
-    env = dict(os.environ, GPAK_FORCE_DIST="1", GPAK_DIST_IMPL="python")   # the round-1 Python schedule (test harness)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps",
-           "2", "--warmup", "1", "--size", "4096", "--no-cpu"]
-    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
-    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 1 and d["unit"] == "steps/s" and d["value"] > 0 and "roofline" in d
-    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--n",
-                             "4096", "--no-cpu"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert single.returncode == 0, single.stderr.decode()[-2000:]
-    s = json.loads([l for l in single.stdout.decode().splitlines() if l.startswith("{")][-1])
-    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_distributed_entry_point_with_several_ranks(world):
-    """bench.py --gpus N as the driver launches it, N ranks rehearsed on this box's one GPU over gloo
-    (sub-panel pipeline on, RCCL replaced by gloo): same nlZ as the single-context path, one JSON line."""
-    root = os.path.dirname(HERE)
-    env = dict(os.environ, GPAK_DIST_BACKEND="gloo", GPAK_DIST_DEVICE="0", GPAK_DIST_IMPL="python")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
-           "--steps", "2", "--warmup", "1", "--size", "4096", "--no-cpu"]
-    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert out.returncode == 0, out.stderr.decode()[-3000:]
-    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                   # rank 0 only
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["bytes_broadcast_per_step"] > 0
-    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--n",
-                             "4096", "--no-cpu"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    s = json.loads([l for l in single.stdout.decode().splitlines() if l.startswith("{")][-1])
-    assert abs(d["nlz"] - s["nlz"]) <= 1e-9 * abs(s["nlz"])

@@ -2,7 +2,10 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gp_ss_ak_amd import multigpu, synth
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import py_schedule as multigpu
+from gp_ss_ak_amd import synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 eng = multigpu.HipEngine(0)
 X, y = synth.drillholes(N)

@@ -4,7 +4,9 @@ a 30 ms burst: TFLOP/s per group of launches over time, with rocm-smi power / cl
 import json, os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gp_ss_ak_amd import multigpu
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import py_schedule as multigpu
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 Np = int(sys.argv[2]) if len(sys.argv) > 2 else 32768

@@ -2,7 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gp_ss_ak_amd import multigpu
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import py_schedule as multigpu
 
 eng = multigpu.HipEngine(0)
 DATA = sys.argv[1] if len(sys.argv) > 1 else "random"

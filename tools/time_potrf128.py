@@ -2,7 +2,9 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gp_ss_ak_amd import multigpu
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import py_schedule as multigpu
 eng = multigpu.HipEngine(0)
 rng = np.random.default_rng(0)
 G = rng.normal(size=(128, 128)); A = G @ G.T + 128 * np.eye(128)

@@ -2,7 +2,10 @@ import sys, os, ctypes as C
 sys.path.insert(0, "/root/repo") if os.path.exists("/root/repo") else None
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
-from gp_ss_ak_amd import multigpu, _lib
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import py_schedule as multigpu
+from gp_ss_ak_amd import _lib
 eng = multigpu.HipEngine(0)
 lib = _lib.load()
 rng = np.random.default_rng(0)
