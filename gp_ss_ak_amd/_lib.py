@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpak_hip.so")
+# GPAK_LIB_PATH: tests load a sanitizer build of the same sources (csrc/Makefile targets tsan / asan); never a fallback
+LIB_PATH = os.environ.get("GPAK_LIB_PATH") or os.path.join(_HERE, "libgpak_hip.so")
 
 # every symbol include/gpak.h declares (tests check the header and this list agree)
 SYMBOLS = [

@@ -14,7 +14,8 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
                       long pool_M);
 // multi.hip
 #include <functional>
-int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision, std::string &err);
+int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision, std::string &err,
+                      const gpak_dist_engine *const *engines);
 void gpak_multi_destroy(gpak_multi *g);
 const char *gpak_multi_error(gpak_multi *g);
 int gpak_multi_set_train(gpak_multi *g, const double *X, const double *y, int N, int d);
@@ -186,11 +187,29 @@ int gpak_create_multi(gpak_ctx **out, int n_gpus, const int *devices, int precis
   *out = nullptr;
   if (precision != GPAK_F64 && precision != GPAK_F32) { g_global_err = "precision must be GPAK_F64 or GPAK_F32"; return GPAK_EINVAL; }
   gpak_multi *g = nullptr;
-  int rc = gpak_multi_create(&g, n_gpus, devices, precision, g_global_err);
+  int rc = gpak_multi_create(&g, n_gpus, devices, precision, g_global_err, nullptr);
   if (rc) return rc;
   gpak_ctx *ctx = new gpak_ctx();
   ctx->multi = g;
   ctx->precision = precision;
+  memset(&ctx->times, 0, sizeof(ctx->times));
+  *out = ctx;
+  return GPAK_OK;
+}
+
+// TEST entry point (gpak_dist.h): the same group -- one host thread per rank, the in-process transport, the gpak_ctx
+// surface of logLikelihood / alpha / gradient -- over caller-supplied engines, so that the thread-per-GPU host logic
+// can be exercised (and run under ThreadSanitizer / AddressSanitizer) on a box without a GPU.
+int gpak_create_multi_with_engines(gpak_ctx **out, int n_ranks, const gpak_dist_engine *const *engines) {
+  if (!out || n_ranks < 1 || !engines) return GPAK_EINVAL;
+  *out = nullptr;
+  for (int r = 0; r < n_ranks; r++) if (!engines[r]) return GPAK_EINVAL;
+  gpak_multi *g = nullptr;
+  int rc = gpak_multi_create(&g, n_ranks, nullptr, GPAK_F64, g_global_err, engines);
+  if (rc) return rc;
+  gpak_ctx *ctx = new gpak_ctx();
+  ctx->multi = g;
+  ctx->precision = GPAK_F64;
   memset(&ctx->times, 0, sizeof(ctx->times));
   *out = ctx;
   return GPAK_OK;

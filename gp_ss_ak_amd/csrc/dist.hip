@@ -952,6 +952,17 @@ int gpak_dist_get_stats(gpak_dist *h, gpak_dist_stats *out) {
 
 }  // extern "C"
 
+// internal: the memory / stream / event entries of the built-in HIP engine alone (none of them uses `self`), for the
+// in-process transport of multi.hip
+void gpak_dist_hip_services(gpak_dist_engine *e) {
+  memset(e, 0, sizeof(*e));
+  e->alloc = he_alloc; e->release = he_release; e->upload = he_upload; e->download = he_download;
+  e->zero = he_zero; e->copy = he_copy;
+  e->stream_destroy = he_stream_destroy;
+  e->event_create = he_event_create; e->event_destroy = he_event_destroy; e->event_record = he_event_record;
+  e->stream_wait_event = he_stream_wait_event; e->stream_sync = he_stream_sync; e->event_elapsed_ms = he_event_elapsed;
+}
+
 // internal (gpak_internal.h): what multi.hip needs to hand this rank's copy of the factor to a single-GPU context
 int gpak_dist_factor_view_get(gpak_dist *h, gpak_dist_factor_view *out) {
   if (!h || !out) return GPAK_EINVAL;

@@ -28,6 +28,7 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
 extern "C" int gpak_dist_rccl_init_all(int n, const int *devices, void **comms, std::string &err);
 extern "C" void gpak_dist_rccl_destroy(void *comm);
 extern "C" int gpak_dist_adopt_rccl(gpak_dist *h, void *comm);
+void gpak_dist_hip_services(gpak_dist_engine *e);   // memory / stream / event entries of the built-in HIP engine
 
 namespace {
 
@@ -42,9 +43,9 @@ struct LocalGroup {
     long seq = -1;
     const void *src = nullptr;
     int src_dev = 0;
-    hipEvent_t ready = nullptr;
+    void *ready = nullptr;
     int acks = 0;
-    std::vector<hipEvent_t> copied;
+    std::vector<void *> copied;
   } slot;
   // all-reduce staging
   std::vector<std::vector<double>> stage_d;
@@ -62,19 +63,23 @@ struct LocalRank {
   LocalGroup *g = nullptr;
   int rank = 0, dev = 0;
   long seq = 0;
-  hipEvent_t ready = nullptr, copied = nullptr;
+  // memory / stream / event services of the rank's engine (the HIP services of dist.hip, or a test's callback table):
+  // the rendezvous below never calls HIP itself, so a CPU harness can drive it thread per rank under a sanitizer
+  gpak_dist_engine E;
+  bool hip = false;            // built-in HIP engine: buffers of different devices are copied with hipMemcpyPeerAsync
+  void *ready = nullptr, *copied = nullptr;
 };
 
 int lt_bcast(void *self, void *st, double *buf, size_t count, int root) {
   LocalRank *r = (LocalRank *)self;
   LocalGroup *g = r->g;
   if (g->P == 1) return GPAK_OK;
+  const gpak_dist_engine &E = r->E;
   const long seq = r->seq++;
-  hipStream_t s = (hipStream_t)st;
   LocalGroup::Slot &sl = g->slot;
   std::unique_lock<std::mutex> lk(g->m);
   if (r->rank == root) {
-    if (hipEventRecord(r->ready, s) != hipSuccess) return GPAK_EHIP;
+    if (E.event_record(E.self, r->ready, st) != GPAK_OK) return GPAK_EHIP;
     g->cv.wait(lk, [&] { return !sl.active; });                 // the previous broadcast has drained
     sl.active = true; sl.root_done = false; sl.seq = seq; sl.src = buf; sl.src_dev = r->dev; sl.ready = r->ready;
     sl.acks = 0;
@@ -83,8 +88,8 @@ int lt_bcast(void *self, void *st, double *buf, size_t count, int root) {
     // the broadcast is complete on the root's stream once every receiver has read the buffer
     g->cv.wait(lk, [&] { return (int)sl.copied.size() == g->P - 1; });
     int rc = GPAK_OK;
-    for (hipEvent_t e : sl.copied)
-      if (hipStreamWaitEvent(s, e, 0) != hipSuccess) rc = GPAK_EHIP;
+    for (void *e : sl.copied)
+      if (E.stream_wait_event(E.self, st, e) != GPAK_OK) rc = GPAK_EHIP;
     sl.root_done = true;
     g->cv.notify_all();
     return rc;
@@ -92,13 +97,16 @@ int lt_bcast(void *self, void *st, double *buf, size_t count, int root) {
   g->cv.wait(lk, [&] { return sl.active && sl.seq == seq; });
   const void *src = sl.src;
   const int src_dev = sl.src_dev;
-  hipEvent_t ready = sl.ready;
+  void *ready = sl.ready;
   lk.unlock();
   int rc = GPAK_OK;
-  if (hipStreamWaitEvent(s, ready, 0) != hipSuccess) rc = GPAK_EHIP;
-  hipError_t e = (src_dev == r->dev) ? hipMemcpyAsync(buf, src, sizeof(double) * count, hipMemcpyDeviceToDevice, s)
-                                     : hipMemcpyPeerAsync(buf, r->dev, src, src_dev, sizeof(double) * count, s);
-  if (e != hipSuccess || hipEventRecord(r->copied, s) != hipSuccess) rc = GPAK_EHIP;
+  if (E.stream_wait_event(E.self, st, ready) != GPAK_OK) rc = GPAK_EHIP;
+  if (r->hip && src_dev != r->dev) {
+    if (hipMemcpyPeerAsync(buf, r->dev, src, src_dev, sizeof(double) * count, (hipStream_t)st) != hipSuccess) rc = GPAK_EHIP;
+  } else if (E.copy(E.self, st, buf, src, sizeof(double) * count) != GPAK_OK) {
+    rc = GPAK_EHIP;
+  }
+  if (E.event_record(E.self, r->copied, st) != GPAK_OK) rc = GPAK_EHIP;
   lk.lock();
   sl.copied.push_back(r->copied);
   g->cv.notify_all();
@@ -109,12 +117,12 @@ int lt_bcast(void *self, void *st, double *buf, size_t count, int root) {
 }
 
 template <typename T, typename Op>
-int lt_allreduce(LocalRank *r, hipStream_t s, T *buf, size_t count, std::vector<std::vector<T>> &stage, Op op) {
+int lt_allreduce(LocalRank *r, void *s, T *buf, size_t count, std::vector<std::vector<T>> &stage, Op op) {
   LocalGroup *g = r->g;
   if (g->P == 1) return GPAK_OK;
+  const gpak_dist_engine &E = r->E;
   std::vector<T> mine(count);
-  if (hipMemcpyAsync(mine.data(), buf, sizeof(T) * count, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess) return GPAK_EHIP;
+  if (E.download(E.self, s, mine.data(), buf, sizeof(T) * count) != GPAK_OK) return GPAK_EHIP;   // complete on return
   std::vector<T> out(count);
   {
     std::unique_lock<std::mutex> lk(g->m);
@@ -125,17 +133,17 @@ int lt_allreduce(LocalRank *r, hipStream_t s, T *buf, size_t count, std::vector<
       for (size_t i = 0; i < count; i++) out[i] = op(out[i], stage[q][i]);
     g->barrier(lk);                           // nobody overwrites its stage entry before everyone has read it
   }
-  if (hipMemcpyAsync(buf, out.data(), sizeof(T) * count, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess) return GPAK_EHIP;
+  if (E.upload(E.self, s, buf, out.data(), sizeof(T) * count) != GPAK_OK || E.stream_sync(E.self, s) != GPAK_OK)
+    return GPAK_EHIP;                         // `out` is a local: the copy must have left it before this returns
   return GPAK_OK;
 }
 int lt_allreduce_sum(void *self, void *st, double *buf, size_t count) {
   LocalRank *r = (LocalRank *)self;
-  return lt_allreduce(r, (hipStream_t)st, buf, count, r->g->stage_d, [](double a, double b) { return a + b; });
+  return lt_allreduce(r, st, buf, count, r->g->stage_d, [](double a, double b) { return a + b; });
 }
 int lt_allreduce_min_int(void *self, void *st, int *buf, size_t count) {
   LocalRank *r = (LocalRank *)self;
-  return lt_allreduce(r, (hipStream_t)st, buf, count, r->g->stage_i, [](int a, int b) { return a < b ? a : b; });
+  return lt_allreduce(r, st, buf, count, r->g->stage_i, [](int a, int b) { return a < b ? a : b; });
 }
 
 }  // namespace
@@ -150,6 +158,7 @@ struct gpak_multi {
   std::vector<LocalRank> local_ranks;
   LocalGroup local;
   bool use_rccl = false;
+  std::vector<gpak_dist_engine> test_engines;   // gpak_create_multi_with_engines: caller-supplied engine per rank (tests)
   std::string transport_name;
   // worker threads and the job they all run
   std::vector<std::thread> threads;
@@ -198,7 +207,7 @@ struct gpak_multi {
     return GPAK_OK;
   }
   void worker(int r) {
-    hipSetDevice(devices[r]);
+    if (test_engines.empty()) hipSetDevice(devices[r]);
     long seen = 0;
     for (;;) {
       std::function<int(int)> f;
@@ -218,6 +227,7 @@ struct gpak_multi {
 };
 
 static int ensure_replica(gpak_multi *g, int r) {
+  if (!g->test_engines.empty()) return g->fail(r, GPAK_ENOTIMPL, "a group over caller-supplied engines has no device replicas");
   if (!g->replicas[r]) {
     int rc = gpak_create(&g->replicas[r], g->devices[r], g->precision);
     if (rc) return g->fail(r, rc, std::string("replica context: ") + gpak_global_error());
@@ -245,8 +255,10 @@ void gpak_multi_destroy(gpak_multi *g) {
   g->run([&](int r) {
     if (g->ranks[r]) gpak_dist_destroy(g->ranks[r]);
     if (g->replicas[r]) gpak_destroy(g->replicas[r]);
-    if (g->local_ranks[r].ready) hipEventDestroy(g->local_ranks[r].ready);
-    if (g->local_ranks[r].copied) hipEventDestroy(g->local_ranks[r].copied);
+    LocalRank &lr = g->local_ranks[r];
+    if (lr.ready) lr.E.event_destroy(lr.E.self, lr.ready);
+    if (lr.copied) lr.E.event_destroy(lr.E.self, lr.copied);
+    lr.ready = lr.copied = nullptr;
     return GPAK_OK;
   });
   {
@@ -258,12 +270,17 @@ void gpak_multi_destroy(gpak_multi *g) {
   delete g;
 }
 
-int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision, std::string &err) {
+// engines: nullptr (the product: built-in HIP engine per device) or n caller-supplied tables (tests: the thread-per-rank
+// host logic and the in-process transport driven on a box without a GPU, e.g. under a sanitizer)
+int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision, std::string &err,
+                      const gpak_dist_engine *const *engines) {
   *out = nullptr;
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { err = "no HIP device available (libgpak_hip has no CPU fallback)"; return GPAK_EHIP; }
+  if (engines) count = n;
+  else if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { err = "no HIP device available (libgpak_hip has no CPU fallback)"; return GPAK_EHIP; }
   gpak_multi *g = new gpak_multi();
   g->P = n; g->precision = precision;
+  if (engines) for (int r = 0; r < n; r++) g->test_engines.push_back(*engines[r]);
   // GPAK_MULTI_DEVICES="0,0,...": ordinals for a caller that passes none (the CLI) -- tests rehearse several ranks on
   // the one GPU of a test box with it
   std::vector<int> from_env;
@@ -288,7 +305,7 @@ int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision
   // RCCL needs one device per rank; several ranks on one device (a test box) use the in-process transport
   const bool distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == (size_t)n;
   const char *tr = getenv("GPAK_MULTI_TRANSPORT");
-  g->use_rccl = n > 1 && distinct && !(tr && !strcmp(tr, "local"));
+  g->use_rccl = n > 1 && distinct && !engines && !(tr && !strcmp(tr, "local"));
   // Whether RCCL can be used is decided HERE, on the caller's thread, before any rank exists: ncclCommInitAll makes
   // the communicators of all ranks in one call -- all of them or none -- so no worker can be left waiting in a
   // rendezvous that a failed peer never joins (ncclCommInitRank per thread had exactly that failure mode).
@@ -308,12 +325,16 @@ int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision
       if (g->ranks[r]) { gpak_dist_destroy(g->ranks[r]); g->ranks[r] = nullptr; }
       LocalRank &lr = g->local_ranks[r];
       lr.g = &g->local; lr.rank = r; lr.dev = g->devices[r]; lr.seq = 0;
-      if (!lr.ready && (hipEventCreateWithFlags(&lr.ready, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&lr.copied, hipEventDisableTiming) != hipSuccess))
-        return g->fail(r, GPAK_EHIP, "hipEventCreate failed");
+      if (!lr.ready) {
+        lr.hip = g->test_engines.empty();
+        if (lr.hip) gpak_dist_hip_services(&lr.E); else lr.E = g->test_engines[r];
+        lr.ready = lr.E.event_create(lr.E.self, 0);
+        lr.copied = lr.E.event_create(lr.E.self, 0);
+        if (!lr.ready || !lr.copied) return g->fail(r, GPAK_EHIP, "event creation failed");
+      }
       // the in-process transport pulls with hipMemcpyPeerAsync: map every other device of the group into this one
       // (without it the copy is staged through the host by the runtime -- correct, but not what xGMI is for)
-      if (attempt == 0)
+      if (attempt == 0 && lr.hip)
         for (int q = 0; q < g->P; q++) {
           if (g->devices[q] == g->devices[r]) continue;
           int can = 0;
@@ -325,7 +346,7 @@ int gpak_multi_create(gpak_multi **out, int n, const int *devices, int precision
         }
       gpak_dist_transport t;
       t.self = &lr; t.bcast = lt_bcast; t.allreduce_sum = lt_allreduce_sum; t.allreduce_min_int = lt_allreduce_min_int;
-      int v = gpak_dist_create(&g->ranks[r], r, g->P, g->devices[r], nullptr, g->use_rccl ? nullptr : &t);
+      int v = gpak_dist_create(&g->ranks[r], r, g->P, g->devices[r], lr.hip ? nullptr : &lr.E, g->use_rccl ? nullptr : &t);
       if (v) return g->fail(r, v, "gpak_dist_create failed");
       if (g->use_rccl) {
         v = gpak_dist_adopt_rccl(g->ranks[r], comms[r]);   // the handle owns the communicator from here on

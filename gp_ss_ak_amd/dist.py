@@ -87,7 +87,7 @@ class Stats(C.Structure):
 DIST_SYMBOLS = ["gpak_dist_create", "gpak_dist_destroy", "gpak_dist_last_error", "gpak_dist_rccl_unique_id",
                 "gpak_dist_init_rccl", "gpak_dist_selfcheck", "gpak_dist_set_train", "gpak_dist_set_params",
                 "gpak_dist_nlz", "gpak_dist_nlz_terms", "gpak_dist_grad", "gpak_dist_get_alpha", "gpak_dist_get_stats",
-                "gpak_dist_failed_column", "gpak_group_rank_stats",
+                "gpak_dist_failed_column", "gpak_group_rank_stats", "gpak_create_multi_with_engines",
                 "gpak_dev_vec_scale", "gpak_dev_vec_sum"]
 
 

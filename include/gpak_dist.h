@@ -34,6 +34,7 @@ extern "C" {
 #endif
 
 typedef struct gpak_dist gpak_dist;
+struct gpak_ctx;   /* gpak.h */
 
 /* Tile engine: memory / stream / event services + the tile operations of gpak_dev.h (same argument lists).
  * Device buffers are opaque addresses; `stream` / `event` are opaque handles of the engine. */
@@ -158,8 +159,13 @@ typedef struct {
 } gpak_dist_stats;
 int gpak_dist_get_stats(gpak_dist *h, gpak_dist_stats *out);
 /* the same for rank `rank` of a multi-GPU context made by gpak_create_multi (gpak.h); GPAK_EINVAL for a one-GPU context */
-struct gpak_ctx;
 int gpak_group_rank_stats(struct gpak_ctx *ctx, int rank, gpak_dist_stats *out);
+
+/* TEST entry point: a gpak_create_multi group (one host thread per rank, in-process transport, the gpak_ctx surface of
+ * logLikelihood / alpha / gradient; no prediction: there are no device replicas) over n_ranks CALLER-SUPPLIED engines.
+ * Lets the thread-per-GPU host logic of csrc/multi.hip run on a box without a GPU, e.g. under ThreadSanitizer
+ * (tests/test_sanitizers.py with the NumPy engine). */
+int gpak_create_multi_with_engines(struct gpak_ctx **out, int n_ranks, const gpak_dist_engine *const *engines);
 
 /* vector helpers of the built-in engine (also in the engine table) */
 int gpak_dev_vec_scale(void *stream, int n, const double *in, double s, double *out);
