@@ -15,7 +15,7 @@ SYMBOLS = [
     "gpak_create", "gpak_create_multi", "gpak_n_gpus", "gpak_transport", "gpak_destroy", "gpak_last_error", "gpak_global_error", "gpak_set_train",
     "gpak_set_params", "gpak_set_kernel", "gpak_set_option", "gpak_gram", "gpak_compute_k", "gpak_factor",
     "gpak_get_chol_upper", "gpak_failed_column", "gpak_solve_alpha", "gpak_solve_chol", "gpak_nlz",
-    "gpak_nlz_terms", "gpak_predict", "gpak_grad", "gpak_grad_hyb", "gpak_timing", "gpak_calibrate",
+    "gpak_nlz_terms", "gpak_predict", "gpak_grad", "gpak_grad_hyb", "gpak_timing", "gpak_calibrate", "gpak_reload_tuning",
 ]
 
 
@@ -74,5 +74,6 @@ def load():
     lib.gpak_grad_hyb.argtypes = [vp, dp, C.c_int]
     lib.gpak_timing.argtypes = [vp, C.POINTER(PhaseTimes)]
     lib.gpak_calibrate.argtypes = [vp, dp, dp]
+    lib.gpak_reload_tuning.restype = None
     _lib = lib
     return lib

@@ -36,6 +36,52 @@ int gpak_grad_impl(gpak_ctx *ctx, double *g, int ng);
 
 static std::string g_global_err;
 
+// ---- the tuning set (gpak_internal.h): defaults, overridden once by the GPAK_* environment ------------------
+static GpakTuning read_tuning_env() {
+  GpakTuning t;
+  auto geti = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
+  auto getb = [](const char *name, bool &v) { if (const char *e = getenv(name)) v = atoi(e) != 0; };
+  geti("GPAK_NB_OUTER", t.nb_outer);
+  geti("GPAK_NB_WIDE", t.nb_wide); t.nb_wide = t.nb_wide / GPAK_TILE * GPAK_TILE;
+  geti("GPAK_NB_WIDE_ROWS", t.nb_wide_rows);
+  getb("GPAK_FIRST_NARROW", t.first_narrow);
+  geti("GPAK_TAIL_ROWS", t.tail_rows);
+  getb("GPAK_SUB_NEXT", t.sub_next);
+  getb("GPAK_INV512", t.inv512);
+  getb("GPAK_LOOKAHEAD", t.lookahead);
+  getb("GPAK_FWD_IN_FACTOR", t.fwd_in_factor);
+  geti("GPAK_POTRF_CO", t.potrf_co);
+  geti("GPAK_TAIL_MASK", t.tail_mask);
+  geti("GPAK_TAIL_MASK_STRIDE", t.tail_mask_stride);
+  getb("GPAK_BULK_QUEUE", t.bulk_queue);
+  if (const char *e = getenv("GPAK_LD_PAD")) t.ld_pad = atol(e) / 2 * 2;
+  geti("GPAK_GEMM_SMALL", t.gemm_small);
+  geti("GPAK_GEMM_SMALL_ROWS", t.gemm_small_rows);
+  getb("GPAK_FILL_FAST", t.fill_fast);
+  getb("GPAK_KMV_SYM", t.kmv_sym);
+  if (const char *e = getenv("GPAK_F32_ACC")) t.f32_wide = strcmp(e, "plain") != 0;
+  geti("GPAK_F32_RSD", t.f32_rsd);
+  geti("GPAK_F32_TILE", t.f32_tile);
+  geti("GPAK_PRED_BATCH", t.pred_batch);
+  if (const char *e = getenv("GPAK_FS_LEVELS_F32")) {   // "128,512,...": ascending, each a multiple of the one before
+    int n = 0, lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const char *p = e; *p && n < 8;) {
+      const int v = atoi(p);
+      if (v >= GPAK_TILE && v % GPAK_TILE == 0 && (n == 0 ? v == GPAK_TILE : v > lv[n - 1] && v % lv[n - 1] == 0)) lv[n++] = v;
+      while (*p && *p != ',') p++;
+      if (*p == ',') p++;
+    }
+    if (n > 0) memcpy(t.fs_levels, lv, sizeof(lv));
+  }
+  return t;
+}
+static GpakTuning &tuning_storage() {
+  static GpakTuning t = read_tuning_env();
+  return t;
+}
+const GpakTuning &gpak_tuning() { return tuning_storage(); }
+extern "C" void gpak_reload_tuning(void) { tuning_storage() = read_tuning_env(); }
+
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static void free_points(DevPoints &p) {
@@ -132,6 +178,7 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
     return GPAK_EHIP;
   }
   gpak_ctx *ctx = new gpak_ctx();
+  ctx->tune = gpak_tuning();
   ctx->device = device;
   ctx->precision = precision;
   memset(&ctx->times, 0, sizeof(ctx->times));
@@ -146,11 +193,10 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   // a copy of the main stream that may not use the first GPAK_TAIL_MASK (default 8) compute units; the bulk
   // updates of the chain-bound tail of the factorisation go there so that the panel chain finds idle CUs
   {
-    const char *tm = getenv("GPAK_TAIL_MASK");       // 0 switches it off
-    const int skip = tm ? atoi(tm) : 8;              // measured: 8 CUs, rows <= 12288: 183.4 -> 181.2 ms
+    const int skip = ctx->tune.tail_mask;            // 0 switches it off; measured: 8 CUs, rows <= 12288: 183.4 -> 181.2 ms
     if (skip > 0 && skip < prop.multiProcessorCount) {
       std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
-      const int stride = getenv("GPAK_TAIL_MASK_STRIDE") ? atoi(getenv("GPAK_TAIL_MASK_STRIDE")) : 1;
+      const int stride = ctx->tune.tail_mask_stride;
       for (int c = 0; c < skip; c++) { const int bit = (c * stride) % prop.multiProcessorCount; mask[bit / 32] &= ~(1u << (bit % 32)); }
       if (hipExtStreamCreateWithCUMask(&ctx->stream_tail, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         ctx->stream_tail = nullptr;
@@ -164,7 +210,7 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   // the middle of the factorisation with nothing else running, on a queue created by hipExtStreamCreateWithCUMask
   // 23 us: 175.1 -> 172.8 ms per factorisation at N = 32768 (same-box A/B).  The same for the panel stream (which then
   // loses its priority): 203 ms; for the forward-substitution or the main stream: +1.3 ms.  GPAK_BULK_QUEUE=0: off.
-  if (!(getenv("GPAK_BULK_QUEUE") && atoi(getenv("GPAK_BULK_QUEUE")) == 0)) {
+  if (ctx->tune.bulk_queue) {
     std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
     if (hipExtStreamCreateWithCUMask(&ctx->stream_bulk, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
       ctx->stream_bulk = nullptr;
@@ -174,10 +220,9 @@ int gpak_create(gpak_ctx **out, int device, int precision) {
   for (int i = 0; i < 10; i++) hipEventCreate(&ctx->ev[i]);
   hipMalloc(&ctx->dRed, sizeof(double) * 64);
   hipMalloc(&ctx->dInfo, sizeof(int) * 4);
-  if (const char *pe = getenv("GPAK_FWD_IN_FACTOR")) ctx->fwd_in_factor = atoi(pe) != 0;
-  if (const char *pe = getenv("GPAK_LOOKAHEAD")) ctx->lookahead = atoi(pe) != 0;   // diagnostics: 0 = one stream
-  const char *nb = getenv("GPAK_NB_OUTER");
-  if (nb) ctx->nb_outer = atoi(nb);
+  ctx->fwd_in_factor = ctx->tune.fwd_in_factor;
+  ctx->lookahead = ctx->tune.lookahead;   // diagnostics: 0 = one stream
+  ctx->nb_outer = ctx->tune.nb_outer;
   *out = ctx;
   return GPAK_OK;
 }
@@ -249,6 +294,19 @@ int gpak_set_option(gpak_ctx *ctx, int option, long value) {
       return GPAK_OK;
     case GPAK_OPT_PROFILE: ctx->profile = value != 0; return GPAK_OK;
     case GPAK_OPT_LOOKAHEAD: ctx->lookahead = value != 0; return GPAK_OK;
+    case GPAK_OPT_NB_WIDE:
+      if (value < 0 || value % 128) { ctx->err = "nb_wide must be 0 or a multiple of 128"; return GPAK_EINVAL; }
+      ctx->tune.nb_wide = (int)value;
+      return GPAK_OK;
+    case GPAK_OPT_NB_WIDE_ROWS: ctx->tune.nb_wide_rows = (int)value; return GPAK_OK;
+    case GPAK_OPT_TAIL_ROWS: ctx->tune.tail_rows = (int)value; return GPAK_OK;
+    case GPAK_OPT_FIRST_NARROW: ctx->tune.first_narrow = value != 0; return GPAK_OK;
+    case GPAK_OPT_INV512: ctx->tune.inv512 = value != 0; return GPAK_OK;
+    case GPAK_OPT_POTRF_CO:
+      if (value < 0 || value > 2) { ctx->err = "potrf_co must be 0, 1 or 2"; return GPAK_EINVAL; }
+      ctx->tune.potrf_co = (int)value;
+      return GPAK_OK;
+    case GPAK_OPT_PRED_BATCH: ctx->tune.pred_batch = (int)value; return GPAK_OK;
   }
   ctx->err = "unknown option";
   return GPAK_EINVAL;
@@ -263,7 +321,7 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
   release_train(ctx);
   const int Np = round_up(N, GPAK_TILE);
   long pad = Np >= 1024 ? 32 : 0;
-  if (const char *p = getenv("GPAK_LD_PAD")) pad = atol(p) / 2 * 2;
+  if (ctx->tune.ld_pad >= 0) pad = ctx->tune.ld_pad;
   const long ld = Np + pad;
   ctx->N = N; ctx->Np = Np; ctx->ld = (int)ld; ctx->d = d;
   ctx->hX.assign(X, X + (size_t)N * d);
@@ -429,7 +487,7 @@ static int ensure_factor(gpak_ctx *ctx) {
   if (rc) return rc;
   ctx->mstate = gpak_ctx::M_L;
   ctx->z_ok = ctx->fwd_in_factor;
-  ctx->inv512_ok = ctx->fwd_in_factor && !(getenv("GPAK_INV512") && atoi(getenv("GPAK_INV512")) == 0);
+  ctx->inv512_ok = ctx->fwd_in_factor && ctx->tune.inv512;
   return GPAK_OK;
 }
 

@@ -31,167 +31,6 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define KB 16
 #define LDS_LD 144
 
-// ---- LDS-staged kernel (GPAK_GEMM=lds) ---------------------------------------------------
-template <bool TRAILING>
-__global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f64(int K, double alpha,
-                                                            const double *A, long lda, const double *B,
-                                                            long ldb,
-                                                            double beta, double *C, long ldc, int rb0,
-                                                            int cb0, int lower_skip, int mt, int nt, int k0_by_row,
-                                                            int cyc_P, int cyc_rank, int cyc_tpb, int cyc_lt0) {
-  // Workgroup -> tile map, XCD-aware: the dispatcher deals consecutive workgroup ids round-robin
-  // over the 8 XCDs, so id b runs on XCD (b & 7) as that XCD's (b >> 3)-th workgroup.  Each XCD
-  // walks 8x8 super-tiles: the 64 workgroups resident on its 32 CUs (2 per CU) cover one
-  // super-tile and stream the SAME 8 A-row and 8 B-row panels k-slice by k-slice, so the XCD's
-  // 4 MiB L2 serves 7 of every 8 operand reads (placement only affects speed, never results).
-  int ti, tj;
-  {
-    const int b = blockIdx.x, q = b >> 3;
-    const int slot = q & 63;
-    const int ssel = (q >> 6) * 8 + (b & 7);
-    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
-    int si, sj = 0;
-    if (lower_skip) {
-      int rem = ssel;
-      while (sj < SC && rem >= SR - sj) { rem -= SR - sj; sj++; }
-      si = sj + rem;
-    } else {
-      sj = ssel / SR;
-      si = ssel - sj * SR;
-    }
-    if (sj >= SC) return;
-    ti = si * 8 + (slot & 7);
-    tj = sj * 8 + (slot >> 3);
-    if (ti >= mt || tj >= nt) return;
-    if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
-  }
-  // Block-column-cyclic column map (multi-GPU trailing update): the C columns are the rank's
-  // OWN block columns stored side by side; local tile column (cyc_lt0 + tj) belongs to local
-  // block lb = ./tpb, i.e. global block lb*P + rank.  A and B are then addressed by GLOBAL row
-  // tile (virtual base), and tiles above the global diagonal are skipped.
-  int gct = tj;  // tile row of the B operand
-  int art = ti;  // tile row of the A operand
-  if (cyc_P) {
-    const int lt = cyc_lt0 + tj;
-    gct = ((lt / cyc_tpb) * cyc_P + cyc_rank) * cyc_tpb + (lt % cyc_tpb);
-    art = rb0 + ti;
-    if (art < gct) return;
-  }
-  __shared__ double lds[2][2][KB][LDS_LD];
-  const int t = threadIdx.x, lane = t & 63;
-  // the wave index as a SCALAR: everything the LDS-DMA needs (LDS row, k-row of the source) is then
-  // computed on the scalar unit.  Vector ALU instructions share the issue port with the MFMAs; ~35 of
-  // them per stage for address arithmetic cost 6 % of the MFMA rate
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = w & 1, wc = w >> 1;
-  const int l15 = lane & 15, l4 = lane >> 4;
-
-  // source of a 16-B piece = scalar base (tile, k-row) + 32-bit lane offset: the global_load_lds
-  // "saddr + voffset" form, so advancing k is scalar arithmetic
-  const char *Au = reinterpret_cast<const char *>(A + (size_t)art * TM);
-  const char *Bu = reinterpret_cast<const char *>(B + (size_t)gct * TN);
-  const unsigned voff = (unsigned)lane * 16u;
-  const size_t lda8 = (size_t)lda * 8, ldb8 = (size_t)ldb * 8;
-
-  d4 acc[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  const int nstage = K / KB;
-  typedef const __attribute__((address_space(1))) void *gptr_t;
-  typedef __attribute__((address_space(3))) void *lptr_t;
-
-  // Direct-to-LDS staging: one global_load_lds_dwordx4 per wave writes one k-row of a tile
-  // (64 lanes x 16 B = 128 doubles = 1 KiB contiguous in global memory AND in LDS).
-  // Wave w stages k-rows w, w+4, w+8, w+12 of both operands: 8 instructions per stage.
-#define GPAK_STAGE(buf_, kbase_)                                                                  \
-  _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                 \
-    const size_t k_ = (size_t)(kbase_) + w + 4 * s;                                               \
-    __builtin_amdgcn_global_load_lds((gptr_t)(Au + k_ * lda8 + voff),                             \
-                                     (lptr_t)&lds[buf_][0][w + 4 * s][0], 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gptr_t)(Bu + k_ * ldb8 + voff),                             \
-                                     (lptr_t)&lds[buf_][1][w + 4 * s][0], 16, 0, 0);              \
-  }
-
-  // k0_by_row: A (and B) are upper triangular in (row, k), so tile row ti only has k >= ti*128
-  const int st_begin = k0_by_row ? (rb0 + ti) * (TM / KB) : 0;
-  GPAK_STAGE(st_begin & 1, (size_t)st_begin * KB)
-  __syncthreads();  // emits vmcnt(0) for the in-flight LDS-DMA, then the barrier
-
-#define GPAK_COMPUTE(buf_)                                                                          \
-  _Pragma("unroll") for (int kk = 0; kk < KB / 4; kk++) {                                           \
-    double a[4], b[4];                                                                              \
-    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                \
-        a[mi] = lds[buf_][0][kk * 4 + l4][wr * 64 + mi * 16 + l15];                                 \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                                \
-        b[ni] = lds[buf_][1][kk * 4 + l4][wc * 64 + ni * 16 + l15];                                 \
-    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                            \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[mi][ni], 0, 0, 0); \
-  }
-
-  // Two stages per trip so that the buffer index is a compile-time constant (LDS offsets become
-  // immediates, no per-stage vector address arithmetic); st_begin is even (0 or a multiple of 8).
-  int st = st_begin;
-  for (; st + 2 < nstage; st += 2) {
-    // stage st+1 streams into the other buffer while this stage's MFMAs run
-    GPAK_STAGE(1, (size_t)(st + 1) * KB)
-    GPAK_COMPUTE(0)
-    // keep this stage's MFMAs ABOVE the wait+barrier: without the fence hipcc reads all
-    // fragments up front and sinks 61 of the 64 MFMAs below the barrier, so every wave sits
-    // out the full LDS-DMA latency before it computes
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    GPAK_STAGE(0, (size_t)(st + 2) * KB)
-    GPAK_COMPUTE(1)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-  if (st + 2 == nstage) {  // an even number of stages: one more full stage before the last
-    GPAK_STAGE(1, (size_t)(st + 1) * KB)
-    GPAK_COMPUTE(0)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-
-  // last stage: no more staging; the C tile (beta != 0) is fetched underneath its MFMAs
-  // lane holds rows (.. + l15), columns (.. + l4 + 4*reg)
-  double *Cg = C + (size_t)art * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + l4) * ldc;
-  const int lbuf = (nstage - 1) & 1;
-  if (beta == 0.0) {
-    GPAK_COMPUTE(lbuf)
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = alpha * acc[mi][ni][r];
-  } else {
-    GPAK_COMPUTE(lbuf)
-    // read-modify-write of the C tile, 16 rows x 64 columns of the wave's sub-tile at a time
-    // (prefetching a row group under the last stage's MFMAs was tried: with the fragment
-    // prefetch hipcc does there it overflows 256 VGPRs and spills -- slower, not faster)
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-      double c[4][4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) c[ni][r] = Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc];
-#pragma unroll
-      for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          Cg[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = fma(alpha, acc[mi][ni][r], beta * c[ni][r]);
-    }
-  }
-#undef GPAK_STAGE
-#undef GPAK_COMPUTE
-}
-
 // ---------------------------------------------------------------------------------------
 // Register-streaming kernel (the default): no LDS, no barriers.  Every lane fetches the elements of
 // its own MFMA fragments straight from global memory with 16-B loads, RS_D k-steps ahead in a
@@ -489,8 +328,7 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
     nsuper = (long)SR * SC;
   }
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
-  static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
-  static const int small_max = getenv("GPAK_GEMM_SMALL") ? atoi(getenv("GPAK_GEMM_SMALL")) : 160;
+  const int small_max = gpak_tuning().gemm_small;
   long tiles = (long)mt * nt;
   if (lower_skip) {  // valid lower 128-tiles
     tiles = 0;
@@ -502,10 +340,10 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
   }
   // (the bulk trailing update keeps its own kernel whatever its size: it is never on the panel chain, and
   //  one kernel name per role keeps the rocprofv3 statistics and bench.py's event timing comparable)
-  if (!use_lds && !trailing && tiles <= small_max) {
+  if (!trailing && tiles <= small_max) {
     // rows per workgroup: the finest split measured best at every size (N = 4096: 2.38 / 2.49 / 2.69 ms per step with
     // 16 / 32 / 64, N = 8192: 6.64 / 6.69 / 6.95, N = 32768: 181.9 / 182.0 / 182.6); GPAK_GEMM_SMALL_ROWS for A/B runs
-    static const int rows = getenv("GPAK_GEMM_SMALL_ROWS") ? atoi(getenv("GPAK_GEMM_SMALL_ROWS")) : 16;
+    const int rows = gpak_tuning().gemm_small_rows;
     const int ls = lower_skip ? 1 : 0, kr = k0_by_row ? 1 : 0;
     if (rows == 64)
       hipLaunchKernelGGL((gpak_gemm_nt_f64_rs32<2, 2>), dim3((unsigned)(2 * mt * nt)), dim3(512), 0, st, K, alpha, A, lda, B,
@@ -518,18 +356,11 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
                          ldb, beta, C, ldc, row_block0, col_block0, ls, 8 * mt, nt, kr);
     return;
   }
-  // GPAK_GEMM=lds selects the LDS-staged kernel (kept for comparison); default: register streaming
-  if (!use_lds && trailing)
+  if (trailing)
     hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
                        row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
-  else if (!use_lds)
-    hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
-  else if (trailing)
-    hipLaunchKernelGGL(gpak_gemm_nt_f64<true>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
   else
-    hipLaunchKernelGGL(gpak_gemm_nt_f64<false>, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
+    hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
                        row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
 }
 

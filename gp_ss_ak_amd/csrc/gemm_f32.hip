@@ -21,84 +21,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define TN 128
 #define KB32 32
 
-__global__ __launch_bounds__(256, 2) void gpak_gemm_nt_f32(int K, float alpha, const float *A, long lda,
-                                                            const float *B, long ldb, float beta, float *C,
-                                                            long ldc, int mt, int nt) {
-  int ti, tj;
-  {
-    const int b = blockIdx.x, q = b >> 3;
-    const int slot = q & 63;
-    const int ssel = (q >> 6) * 8 + (b & 7);
-    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
-    const int sj = ssel / SR, si = ssel - sj * SR;
-    if (sj >= SC) return;
-    ti = si * 8 + (slot & 7);
-    tj = sj * 8 + (slot >> 3);
-    if (ti >= mt || tj >= nt) return;
-  }
-  __shared__ float lds[2][2][KB32][TM];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wr = w & 1, wc = w >> 1;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  // LDS-DMA piece of a wave instruction: lanes 0..31 -> k-row 2p, lanes 32..63 -> k-row 2p+1
-  const int lrow = (lane & 31) * 4, lk = lane >> 5;
-  const float *Ag = A + (size_t)ti * TM + lrow + (size_t)lk * lda;
-  const float *Bg = B + (size_t)tj * TN + lrow + (size_t)lk * ldb;
-
-  f4 acc[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (f4){0.f, 0.f, 0.f, 0.f};
-
-  const int nstage = K / KB32;
-  typedef const __attribute__((address_space(1))) void *gptr_t;
-  typedef __attribute__((address_space(3))) void *lptr_t;
-  // wave w stages k-row pairs w, w+4, w+8, w+12 (rows 2p, 2p+1) of both operands
-#define GPAK_STAGE32(buf_, kbase_)                                                                   \
-  _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                    \
-    const int p_ = w + 4 * s;                                                                        \
-    const size_t k_ = (size_t)(kbase_) + 2 * p_;                                                     \
-    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + k_ * lda), (lptr_t)&lds[buf_][0][2 * p_][0], 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + k_ * ldb), (lptr_t)&lds[buf_][1][2 * p_][0], 16, 0, 0); \
-  }
-#define GPAK_COMPUTE32(buf_)                                                                         \
-  _Pragma("unroll") for (int kk = 0; kk < KB32 / 4; kk++) {                                          \
-    float a[4], b[4];                                                                                \
-    _Pragma("unroll") for (int mi = 0; mi < 4; mi++) a[mi] = lds[buf_][0][kk * 4 + l4][wr * 64 + mi * 16 + l15]; \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ni++) b[ni] = lds[buf_][1][kk * 4 + l4][wc * 64 + ni * 16 + l15]; \
-    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                 \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                             \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni], a[mi], acc[mi][ni], 0, 0, 0);  \
-  }
-
-  GPAK_STAGE32(0, 0)
-  __syncthreads();
-  for (int st = 0; st + 1 < nstage; st++) {
-    const int buf = st & 1;
-    GPAK_STAGE32(buf ^ 1, (size_t)(st + 1) * KB32)
-    GPAK_COMPUTE32(buf)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-  const int lbuf = (nstage - 1) & 1;
-  GPAK_COMPUTE32(lbuf)
-  // lane holds row (.. + l15), columns (.. + 4*l4 + reg)
-  float *Cg = C + (size_t)ti * TM + wr * 64 + l15 + ((size_t)tj * TN + wc * 64 + 4 * l4) * ldc;
-#pragma unroll
-  for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-    for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float *p = Cg + mi * 16 + (size_t)(ni * 16 + r) * ldc;
-        const float v = alpha * acc[mi][ni][r];
-        *p = (beta == 0.f) ? v : fmaf(beta, *p, v);
-      }
-#undef GPAK_STAGE32
-#undef GPAK_COMPUTE32
-}
-
 // ---------------------------------------------------------------------------------------
 // Register-streaming variant (the default, see gemm.hip): no LDS, no barriers.  One 16-B load per
 // operand and k-step feeds all FOUR of a wave's fragments on that side: lane (l15, l4) fetches rows
@@ -378,24 +300,22 @@ void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha,
   const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
   const long nsuper = (long)SR * SC;
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
-  static const bool use_lds = getenv("GPAK_GEMM") && !strcmp(getenv("GPAK_GEMM"), "lds");
   // Products longer than one chunk take the wide-accumulation kernel (fp32 MFMA chunks of K = 128 summed in fp64):
   // measured at N = 32768, M = 65536 against the fp64 context, variance error 7.4e-7 of the largest variance instead
   // of 6.8e-6, for 118 instead of 120.5 TFLOP/s (profiles/r03_f32_accumulation.txt).  A K = 128 product IS one chunk:
-  // the 128 x 64-tile kernel below computes the same sum faster.  GPAK_F32_ACC=plain: the round-2 kernels everywhere.
-  const char *accm = getenv("GPAK_F32_ACC");
-  const bool wide = !(accm && !strcmp(accm, "plain")) && K > 128 && K % 128 == 0;
+  // the 128 x 64-tile kernel below computes the same sum faster.  GpakTuning::f32_wide = false (GPAK_F32_ACC=plain): the
+  // round-2 kernels everywhere.
+  const GpakTuning &tn = gpak_tuning();
+  const bool wide = tn.f32_wide && K > 128 && K % 128 == 0;
   if (wide) {
-    const int v = getenv("GPAK_F32_RSD") ? atoi(getenv("GPAK_F32_RSD")) : 4;
+    const int v = tn.f32_rsd;
     if (v == 8)        // one workgroup per CU slot pair: all 512 registers of a SIMD lane for one wave
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<8, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
     else if (v == 2)
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<2, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
     else
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<4, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
-  } else if (use_lds)
-    hipLaunchKernelGGL(gpak_gemm_nt_f32, grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
-  else if (!(mt & 1) && (!getenv("GPAK_F32_TILE") || atoi(getenv("GPAK_F32_TILE")) != 64)) {
+  } else if (!(mt & 1) && tn.f32_tile != 64) {
     const int mt2 = mt / 2, SR2 = (mt2 + 7) / 8;
     dim3 grid2((unsigned)(((long)SR2 * SC + 7) / 8 * 8 * 64));
     hipLaunchKernelGGL(gpak_gemm_nt_f32_rs2<4>, grid2, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt2, nt);

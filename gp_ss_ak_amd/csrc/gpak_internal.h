@@ -47,6 +47,41 @@ struct DevPoints {
   int cap = 0;  // allocated points (multiple of GPAK_TILE)
 };
 
+// ---- tuning ------------------------------------------------------------------------------------------------
+// Every schedule / kernel-selection knob of the library in ONE place.  gpak_tuning() is the process-wide set: the
+// defaults below (each the measured best at N = 32768 on MI355X, DESIGN.md sections 4.1-4.4), overridden ONCE, at the
+// first call, by the GPAK_* environment variables of the same names (A/B tooling; gpak_reload_tuning() re-reads
+// them).  A context copies the set at gpak_create; gpak_set_option changes the copy of that context only.
+struct GpakTuning {
+  // gpak_potrf_blocked
+  int nb_outer = 512;          // GPAK_NB_OUTER      outer panel width
+  int nb_wide = 1024;          // GPAK_NB_WIDE       panel width while more than nb_wide_rows rows are left (0: off)
+  int nb_wide_rows = 16384;    // GPAK_NB_WIDE_ROWS
+  bool first_narrow = true;    // GPAK_FIRST_NARROW  the very first panel is nb_outer wide
+  int tail_rows = 12288;       // GPAK_TAIL_ROWS     rows left from which the bulk updates use the CU-masked queue
+  bool sub_next = false;       // GPAK_SUB_NEXT      tail: next block column updated sub-panel by sub-panel
+  bool inv512 = true;          // GPAK_INV512        explicit 512-block inverses for the back substitution
+  bool lookahead = true;       // GPAK_LOOKAHEAD     0: everything on one stream
+  bool fwd_in_factor = true;   // GPAK_FWD_IN_FACTOR forward substitution of y/sn2 rides along with the factorisation
+  int potrf_co = 1;            // GPAK_POTRF_CO      0 always the 8-wave block kernel, 2 always the 4-wave one, 1 as asked
+  int tail_mask = 8;           // GPAK_TAIL_MASK     compute units the tail's bulk queue leaves idle (0: no such queue)
+  int tail_mask_stride = 1;    // GPAK_TAIL_MASK_STRIDE
+  bool bulk_queue = true;      // GPAK_BULK_QUEUE    bulk updates on a queue made by hipExtStreamCreateWithCUMask
+  long ld_pad = -1;            // GPAK_LD_PAD        leading-dimension skew in doubles (-1: 32 from Np = 1024 on)
+  // kernel selection
+  int gemm_small = 160;        // GPAK_GEMM_SMALL      tile grids up to this size take the latency kernel
+  int gemm_small_rows = 16;    // GPAK_GEMM_SMALL_ROWS rows per workgroup of that kernel: 16 / 32 / 64
+  bool fill_fast = true;       // GPAK_FILL_FAST     table exp + in-line sqrt fill / Gram-matvec
+  bool kmv_sym = true;         // GPAK_KMV_SYM       symmetric Gram-matvec from 32 macro blocks on
+  // fp32 prediction (GPAK_F32 contexts)
+  bool f32_wide = true;        // GPAK_F32_ACC=plain switches the fp64 accumulation of the fp32 products off
+  int f32_rsd = 4;             // GPAK_F32_RSD       operand prefetch depth of the wide-accumulation kernel: 2 / 4 / 8
+  int f32_tile = 128;          // GPAK_F32_TILE      wave tile rows of the plain fp32 kernel: 128 / 64
+  int fs_levels[8] = {128, 512, 2048, 8192, 0, 0, 0, 0};   // GPAK_FS_LEVELS_F32  ladder of the fp32 substitution
+  int pred_batch = 0;          // GPAK_PRED_BATCH    test points per batch (0: 16384 fp64, 65536 fp32)
+};
+const GpakTuning &gpak_tuning();
+
 struct gpak_multi;   // multi.hip: one process driving several GPUs (gpak_create_multi)
 
 struct gpak_ctx {
@@ -113,6 +148,7 @@ struct gpak_ctx {
   size_t gpart_elems = 0;
 
   // options
+  GpakTuning tune;            // this context's copy of the tuning set (gpak_set_option changes it)
   bool memoise = false;
   int nb_outer = 512;
   bool profile = false;
@@ -275,10 +311,10 @@ void gpak_launch_rowsumsq_f32(hipStream_t st, const float *V, long ldv, int rows
 // ---- potrf.hip --------------------------------------------------------------------------
 // Factor the 128x128 block at A (ld) in place (lower), write its inverse to inv (128x128, ld 128).
 void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv,
-                          bool co = false);
+                          bool co = false, int co_mode = -1);
 int gpak_potrf_blocked(gpak_ctx *ctx);
 void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                       bool zero_inv, bool co = false);
+                       bool zero_inv, bool co = false, int co_mode = -1);
 
 // ---- solve.hip --------------------------------------------------------------------------
 // x := L^-1 x ; x := L^-T x  (x has Np entries) using the inverted diagonal blocks.

@@ -206,7 +206,7 @@ void gpak_launch_fill(hipStream_t st, const DevPoints &P, const DevPoints &Q, in
                       const KernParams &kp, double scale, double diag, double pad_diag, int lower_only,
                       double *C, long ld, double *D2out, int col_off) {
   dim3 grid(rows_p / FILL_ROWS, cols_p / FILL_COLS);
-  static const bool fast_off = getenv("GPAK_FILL_FAST") && atoi(getenv("GPAK_FILL_FAST")) == 0;
+  const bool fast_off = !gpak_tuning().fill_fast;
   if (kp.nterms == 1 && kp.term[0].profile == GPAK_PROFILE_EXPSQRT && !D2out && !fast_off) {
     const double sv = scale * kp.term[0].var2, sb = scale * kp.bias, dg = diag + kp.white * scale;
 #define GPAK_FILL1(MODE_, D4_)                                                                                        \
@@ -487,8 +487,8 @@ void gpak_launch_kmatvec(hipStream_t st, const DevPoints &P, int p_off, int np, 
   int per = (np + splits - 1) / splits;
   per = (per + KMV_CHUNK - 1) / KMV_CHUNK * KMV_CHUNK;
   dim3 grid((Q.n + 256 * KMV_COLS - 1) / (256 * KMV_COLS), splits);
-  static const bool fast_off = getenv("GPAK_FILL_FAST") && atoi(getenv("GPAK_FILL_FAST")) == 0;
-  static const bool sym_off = getenv("GPAK_KMV_SYM") && atoi(getenv("GPAK_KMV_SYM")) == 0;
+  const bool fast_off = !gpak_tuning().fill_fast;
+  const bool sym_off = !gpak_tuning().kmv_sym;
   // the symmetric kernel: both vectors over the same points, a grid large enough to fill the chip, and its nbm partial
   // rows fit into the scratch (scratch_rows * Q.cap doubles; at least the `splits` rows every caller provides)
   const int nbm = (Q.n + 256 * KSYM_G - 1) / (256 * KSYM_G);

@@ -465,7 +465,8 @@ void gpak_potrf128_co_f64(double *A, long ld, double *__restrict__ inv, int col0
   gpak_potrf128_body<4>(A, ld, inv, col0, info, zero_inv);
 }
 
-void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv, bool co) {
+void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int col0, int *info, bool zero_inv, bool co,
+                          int co_mode) {
   // 132 KiB of dynamic LDS needs the opt-in, once per kernel AND per device (a thread group drives several devices
   // from one process)
   {
@@ -481,8 +482,9 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
       done_mask.fetch_or(bit, std::memory_order_release);
     }
   }
-  // GPAK_POTRF_CO: 0 = always the 8-wave build, 2 = always the co-resident 4-wave build, 1 / unset = as the caller asks
-  static const int co_mode = getenv("GPAK_POTRF_CO") ? atoi(getenv("GPAK_POTRF_CO")) : 1;
+  // co_mode (GpakTuning::potrf_co): 0 = always the 8-wave build, 2 = always the co-resident 4-wave build, 1 = as the
+  // caller asks; -1 = the process-wide setting
+  if (co_mode < 0) co_mode = gpak_tuning().potrf_co;
   if (co_mode != 1) co = co_mode == 2;
   if (co) hipLaunchKernelGGL(gpak_potrf128_co_f64, dim3(1), dim3(256), GPAK_POTRF_LDS_BYTES, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
   else hipLaunchKernelGGL(gpak_potrf128_f64, dim3(1), dim3(512), GPAK_POTRF_LDS_BYTES, st, A, ld, inv, col0, info, zero_inv ? 1 : 0);
@@ -493,10 +495,10 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
 // rank that stores just this block column passes a virtual base (see dev_api.hip).
 // One level: 128-column steps, each followed by the K=128 update of the columns [j+128, J+W).
 static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                             bool zero_inv, bool co) {
+                             bool zero_inv, bool co, int co_mode) {
   for (int j = J; j < J + W; j += PB) {
     double *inv = inv_base + (size_t)(j / PB) * 2 * PB * PB;
-    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info, zero_inv, co);
+    gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info, zero_inv, co, co_mode);
     const int mt = (Np - j - PB) / PB;
     if (mt > 0) {
       double *P = M + (j + PB) + (size_t)j * ld;
@@ -512,10 +514,10 @@ static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, 
 // of the rest of the panel in between (three-level blocking: 128 / MID / W).
 #define GPAK_PANEL_MID 512
 void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                       bool zero_inv, bool co) {
+                       bool zero_inv, bool co, int co_mode) {
   for (int j = J; j < J + W; j += GPAK_PANEL_MID) {
     const int w = (J + W - j) < GPAK_PANEL_MID ? (J + W - j) : GPAK_PANEL_MID;
-    factor_panel_128(st, M, ld, Np, j, w, inv_base, info, zero_inv, co);
+    factor_panel_128(st, M, ld, Np, j, w, inv_base, info, zero_inv, co, co_mode);
     const int c0 = j + w, nct = (J + W - c0) / PB, mt = (Np - c0) / PB;
     if (nct > 0 && mt > 0) {
       const double *P = M + c0 + (size_t)j * ld;
@@ -525,7 +527,7 @@ void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W,
 }
 static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W, bool co) {
   // ctx->dInv is zeroed once in gpak_set_train and only ever written inside its triangles
-  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false, co);
+  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false, co, ctx->tune.potrf_co);
 }
 
 // Chain-bound tail: the same panel factorisation (W <= 512), but the update of the NEXT block column [J1, J2) is
@@ -542,7 +544,7 @@ static int factor_panel_tail(gpak_ctx *ctx, hipStream_t sp, hipStream_t sx, int 
   int k = 0;
   for (int j = J; j < J + W; j += PB, k++) {
     double *inv = ctx->dInv + (size_t)(j / PB) * 2 * PB * PB;
-    gpak_launch_potrf128(sp, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo, false, false);
+    gpak_launch_potrf128(sp, M + j + (size_t)j * ld, ld, inv, j, ctx->dInfo, false, false, ctx->tune.potrf_co);
     const int mt = (Np - j - PB) / PB;
     if (mt <= 0) continue;
     double *P = M + (j + PB) + (size_t)j * ld;
@@ -594,12 +596,12 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   // panel makes it more efficient (K = 1024: 73.7 TFLOP/s in the kernel, K = 512: 71.4); later the narrower
   // panel keeps the chain short (N=32768: 180.8 -> 178.5 ms).  GPAK_NB_WIDE / GPAK_NB_WIDE_ROWS: width and
   // "rows left" threshold; only applies when nb_outer is narrower than the wide width.
-  static const int nb_wide = getenv("GPAK_NB_WIDE") ? atoi(getenv("GPAK_NB_WIDE")) / PB * PB : 1024;   // 0: off
-  static const int nb_wide_rows = getenv("GPAK_NB_WIDE_ROWS") ? atoi(getenv("GPAK_NB_WIDE_ROWS")) : 16384;
+  const int nb_wide = ctx->tune.nb_wide / PB * PB;   // 0: off
+  const int nb_wide_rows = ctx->tune.nb_wide_rows;
   std::vector<int> Js;
   // the very first panel has nothing to hide behind: keep it narrow so that the first bulk update starts early
   // (measured at N=32768, 30-step A/B inside one box: 182.46 -> 181.90 ms)
-  static const bool first_narrow = !(getenv("GPAK_FIRST_NARROW") && atoi(getenv("GPAK_FIRST_NARROW")) == 0);
+  const bool first_narrow = ctx->tune.first_narrow;
   for (int J = 0; J < Np;) {
     Js.push_back(J);
     J += (nb_wide > NB && Np - J > nb_wide_rows && !(first_narrow && J == 0)) ? nb_wide : NB;
@@ -626,11 +628,11 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   int done512 = 0;
   double tflops = 0.0, tbytes = 0.0;
   int tl = 0;
-  static const int tail_rows = getenv("GPAK_TAIL_ROWS") ? atoi(getenv("GPAK_TAIL_ROWS")) : 12288;
+  const int tail_rows = ctx->tune.tail_rows;
   // sub-panel updates of the next block column in the tail (factor_panel_tail): measured 183.07 -> 183.73 ms at
   // N=32768 -- the four K=128 products re-read and re-write the column four times and the chain gains nothing
   // measurable; off unless GPAK_SUB_NEXT=1 (kept: the multi-GPU schedule is built the same way and tests compare)
-  static const bool sub_next = getenv("GPAK_SUB_NEXT") && atoi(getenv("GPAK_SUB_NEXT")) != 0;
+  const bool sub_next = ctx->tune.sub_next;
   bool next_col_done = false;   // the next block column already has this panel's update (applied per sub-panel)
   for (int b = 0; b < nJ; b++) {
     const int J = Js[b], W = Js[b + 1] - J;
@@ -656,7 +658,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
       gpak_launch_trsv_fwd_block(sf, Np, J, W, ctx->dM, ctx->ld, ctx->dInv, ctx->dWork, ctx->dWork + Np);
       // explicit inverses of the 512-column diagonal blocks completed by this panel, for the back substitution
       // (same stream: off the panel chain, hidden behind the bulk updates)
-      static const bool inv512 = !(getenv("GPAK_INV512") && atoi(getenv("GPAK_INV512")) == 0);
+      const bool inv512 = ctx->tune.inv512;
       while (inv512 && done512 * 512 < Np && (std::min(Np, (done512 + 1) * 512) <= J + W)) {
         const int j5 = done512 * 512;
         gpak_launch_diag_inverse(sf, j5, std::min(512, Np - j5), ctx->dM, ctx->ld, ctx->dInv,

@@ -155,17 +155,9 @@ static void fs_block_f32(gpak_ctx *ctx, float *Wt, long ldw, int mt, int J0, int
   }
 }
 static void forward_subst_batch_f32(gpak_ctx *ctx, float *Wt, long ldw, int mbp) {
-  std::vector<int> lv = {PB, 512, 2048, 8192};
-  if (const char *e = getenv("GPAK_FS_LEVELS_F32")) {
-    lv.clear();
-    for (const char *p = e; *p;) {
-      const int v = atoi(p);
-      if (v >= PB && v % PB == 0 && (lv.empty() ? v == PB : v > lv.back() && v % lv.back() == 0)) lv.push_back(v);
-      while (*p && *p != ',') p++;
-      if (*p == ',') p++;
-    }
-    if (lv.empty()) lv = {PB, 512};
-  }
+  std::vector<int> lv;
+  for (int v : ctx->tune.fs_levels) if (v > 0) lv.push_back(v);
+  if (lv.empty()) lv = {PB, 512};
   lv.push_back(ctx->Np > lv.back() ? ctx->Np : lv.back() + 1);   // the whole matrix is the top block
   // the top block's width need not be a multiple of its children's: fs_block_f32 clips the last child
   fs_block_f32(ctx, Wt, ldw, mbp / PB, 0, ctx->Np, lv, (int)lv.size() - 1);
@@ -182,7 +174,7 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
   // 32768 -> 71.7 / 118.7, 65536 -> 71.8 / 119.7: the fp32 path takes the larger batch
   const bool f32 = ctx->precision == GPAK_F32;
   int batch = f32 ? 65536 : 16384;
-  if (const char *e = getenv("GPAK_PRED_BATCH")) batch = std::max(2 * PB, atoi(e) / (2 * PB) * (2 * PB));
+  if (ctx->tune.pred_batch > 0) batch = std::max(2 * PB, ctx->tune.pred_batch / (2 * PB) * (2 * PB));
   // keep the cross-kernel batch under ~8 GiB
   while (batch > 2 * PB && (size_t)batch * Np * (f32 ? sizeof(float) : sizeof(double)) > ((size_t)8 << 30)) batch /= 2;
   batch = batch / (2 * PB) * (2 * PB);

@@ -104,6 +104,15 @@ int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *p
 #define GPAK_OPT_NB_OUTER  2  /* outer Cholesky block width (multiple of 128)              */
 #define GPAK_OPT_PROFILE   3  /* 1: bracket each trailing-update launch with hip events    */
 #define GPAK_OPT_LOOKAHEAD 4  /* 1 (default): factor the next panel beside the bulk update */
+/* schedule of the blocked factorisation (defaults = the measured best at N = 32768; the process-wide
+ * defaults can also be set for A/B runs with the GPAK_* environment variables read ONCE at the first gpak_create) */
+#define GPAK_OPT_NB_WIDE      5  /* panel width while more than NB_WIDE_ROWS rows are left (0: off; default 1024)  */
+#define GPAK_OPT_NB_WIDE_ROWS 6  /* default 16384                                                                   */
+#define GPAK_OPT_TAIL_ROWS    7  /* rows left from which the bulk updates leave 8 compute units idle (12288)        */
+#define GPAK_OPT_FIRST_NARROW 8  /* 1 (default): the very first panel is NB_OUTER wide                              */
+#define GPAK_OPT_INV512       9  /* 1 (default): explicit 512-block inverses for the back substitution             */
+#define GPAK_OPT_POTRF_CO    10  /* 128 x 128 block kernel: 0 always 8 waves, 2 always the 4-wave build, 1 as needed */
+#define GPAK_OPT_PRED_BATCH  11  /* test points per prediction batch (0: 16384 fp64, 65536 fp32)                    */
 int gpak_set_option(gpak_ctx *ctx, int option, long value);
 
 /* ---- hot path --------------------------------------------------------------------------- */
@@ -182,6 +191,10 @@ typedef struct {
   int    evaluations;        /* ... how many evaluations (factorisations) that was               */
 } gpak_phase_times;
 int gpak_timing(gpak_ctx *ctx, gpak_phase_times *out);
+
+/* re-read the GPAK_* tuning environment into the process-wide defaults (A/B tooling inside one process; contexts made
+ * afterwards see it) */
+void gpak_reload_tuning(void);
 
 /* fp64-MFMA and HBM-write calibration microbenchmarks */
 int gpak_calibrate(gpak_ctx *ctx, double *mfma_f64_tflops, double *hbm_write_gbs);

@@ -283,15 +283,16 @@ def test_coincident_points_and_ragged_batches(gp, orc):
 
 
 def test_alternative_kernels_give_the_same_step():
-    """The LDS-staged GEMM (GPAK_GEMM=lds), no CU-masked tail stream, everything on the 64x64-per-wave kernel:
-    same nlZ as the default build of the step (the environment is read once per process, hence subprocesses)."""
+    """No CU-masked tail stream, no separate bulk queue, everything on the 64x64-per-wave kernel, both block kernels,
+    the three workgroup heights of the panel-chain GEMM: same nlZ as the default build of the step (the GPAK_*
+    environment sets the process-wide tuning defaults once, at the first gpak_create, hence subprocesses)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     vals = {}
-    for name, env in (("default", {}), ("lds", {"GPAK_GEMM": "lds"}), ("nomask", {"GPAK_TAIL_MASK": "0"}),
+    for name, env in (("default", {}), ("nomask", {"GPAK_TAIL_MASK": "0"}), ("no_bulk_queue", {"GPAK_BULK_QUEUE": "0"}),
                       ("nosmall", {"GPAK_GEMM_SMALL": "0"}),
                       # the two builds of the 128x128 block kernel (8 waves / 4 waves at 80 VGPRs) and the three
                       # workgroup heights of the panel-chain GEMM
@@ -474,8 +475,14 @@ def test_options_and_two_live_contexts(orc):
         assert abs(ref - info.nlz) <= 1e-9 * abs(info.nlz)
         ib, _, _ = orc.nlz_refseq(np.ascontiguousarray(Ko[:700, :700]), y[:700], SN2)
         assert abs(b.logLikelihood() - ib.nlz) <= 1e-9 * abs(ib.nlz)       # b is untouched by a's work
+        # the schedule knobs that used to be GPAK_* environment variables read inside the factorisation are options of
+        # the context (include/gpak.h): wide panels from the start (the context has 3000 rows: NB_WIDE_ROWS below that
+        # switches them on), no wide panels, tail threshold, block-kernel build, no 512-block inverses
         for opt, val in ((gpak.OPT_LOOKAHEAD, 0), (gpak.OPT_NB_OUTER, 128), (gpak.OPT_NB_OUTER, 256),
-                         (gpak.OPT_NB_OUTER, 1024)):
+                         (gpak.OPT_NB_OUTER, 1024), (gpak.OPT_NB_OUTER, 512), (gpak.OPT_LOOKAHEAD, 1),
+                         (gpak.OPT_NB_WIDE_ROWS, 1024), (gpak.OPT_FIRST_NARROW, 0), (gpak.OPT_NB_WIDE, 0),
+                         (gpak.OPT_TAIL_ROWS, 0), (gpak.OPT_TAIL_ROWS, 1 << 30), (gpak.OPT_POTRF_CO, 0),
+                         (gpak.OPT_POTRF_CO, 2), (gpak.OPT_POTRF_CO, 1), (gpak.OPT_INV512, 0)):
             a.set_option(opt, val)
             a.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)                    # invalidates like the reference
             v = a.logLikelihood()
@@ -483,8 +490,10 @@ def test_options_and_two_live_contexts(orc):
             assert rel(a.solve_alpha(), alpha_o) <= 1e-8
         a.set_option(gpak.OPT_LOOKAHEAD, 1)
         a.set_option(gpak.OPT_NB_OUTER, 512)
-        with pytest.raises(gpak.GpakError):
-            a.set_option(gpak.OPT_NB_OUTER, 100)                            # not a multiple of 128
+        a.set_option(gpak.OPT_INV512, 1)
+        for opt, val in ((gpak.OPT_NB_OUTER, 100), (gpak.OPT_NB_WIDE, 700), (gpak.OPT_POTRF_CO, 3), (99, 1)):
+            with pytest.raises(gpak.GpakError):
+                a.set_option(opt, val)                                      # not a multiple of 128 / out of range / unknown
         a.set_option(gpak.OPT_MEMOISE, 1)
         a.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
         a.logLikelihood()

@@ -35,6 +35,11 @@ for var in VARIANTS:
     for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(var)
+    gpak._lib.load().gpak_reload_tuning()          # the environment sets the process-wide defaults; a context copies them
+    g32.close()
+    g32 = gpak.Gpak(0, gpak.F32)
+    g32.set_train(X, y)
+    g32.set_params(E, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
     g32.posteriorMeanVar(Xte[:512])
     t0 = time.perf_counter()
     m32, v32 = g32.posteriorMeanVar(Xte)
