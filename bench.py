@@ -477,6 +477,8 @@ def main():
                                                                "reference sequence at full size; 0 = skip)")
     ap.add_argument("--config3", type=int, default=3, help="L-BFGS iterations of the configs[2] sub-run through the CLI "
                                                             "(N=32768 only; 0 = skip)")
+    ap.add_argument("--grid", default="auto", help="N > 1: also time the row-block x column-block layouts: PrxPc, 'auto' "
+                                                    "(every Pr in 2, 4, 8 dividing N) or 'none'")
     ap.add_argument("--inproc", action="store_true", help="N > 1: one process, one host thread per GPU (gpak_create_multi)")
     ap.add_argument("--profile-tag", default=os.environ.get("GPAK_PROFILE_TAG", "r03"),
                     help="profiles/<tag>_pmc_summary_N<N>.json supplies `traffic` and the in-situ clock")

@@ -63,6 +63,7 @@ static GpakTuning read_tuning_env() {
   geti("GPAK_F32_RSD", t.f32_rsd);
   geti("GPAK_F32_TILE", t.f32_tile);
   geti("GPAK_PRED_BATCH", t.pred_batch);
+  geti("GPAK_PRED_LD_SKEW", t.pred_ld_skew);
   if (const char *e = getenv("GPAK_FS_LEVELS_F32")) {   // "128,512,...": ascending, each a multiple of the one before
     int n = 0, lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (const char *p = e; *p && n < 8;) {

@@ -40,6 +40,39 @@ __global__ void gpak_pack_f64(const double *__restrict__ src, long ld, int row0,
         *reinterpret_cast<const double2 *>(src + (size_t)c * ld + row0 + r);
 }
 
+// y[0..nrows) += A x, A nrows x W column-major: one thread per row (coalesced along the rows), x in LDS
+__global__ __launch_bounds__(256) void gpak_gemv_n_add_f64(const double *__restrict__ A, long ld, int nrows, int W,
+                                                           const double *__restrict__ x, double *__restrict__ y) {
+  __shared__ double xs[512];
+  for (int c = threadIdx.x; c < W; c += 256) xs[c] = x[c];
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows) return;
+  double s0 = 0.0, s1 = 0.0;
+  int c = 0;
+  for (; c + 1 < W; c += 2) {
+    s0 = fma(A[r + (size_t)c * ld], xs[c], s0);
+    s1 = fma(A[r + (size_t)(c + 1) * ld], xs[c + 1], s1);
+  }
+  if (c < W) s0 = fma(A[r + (size_t)c * ld], xs[c], s0);
+  y[r] += s0 + s1;
+}
+// y[c] = sum_r A[r, c] x[r]: one workgroup per column, fixed-order tree reduction (deterministic)
+__global__ __launch_bounds__(256) void gpak_gemv_t_f64(const double *__restrict__ A, long ld, int nrows,
+                                                       const double *__restrict__ x, double *__restrict__ y) {
+  __shared__ double red[256];
+  const double *col = A + (size_t)blockIdx.x * ld;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) s = fma(col[r], x[r], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) y[blockIdx.x] = red[0];
+}
+
 extern "C" {
 
 int gpak_dev_pack(void *stream, const double *src, long ld, int row0, int nrows, int ncols, double *dst) {
@@ -164,6 +197,67 @@ int gpak_dev_nlz_terms(void *stream, int N, const double *y, const double *f, co
                        double *out) {
   // the launcher writes red[1], red[2]; shift so that they land in out[0], out[1]
   gpak_launch_nlz_terms((hipStream_t)stream, N, y, f, alpha, sn2, out - 1);
+  return status();
+}
+
+// ---- pieces of the row-block x column-block layout (include/gpak_dev.h) --------------------------------------
+int gpak_dev_fill_rect(void *stream, const double *u, int cap, int n, int row0, int nrows, int col0, int ncols,
+                       const double *expans, double bias, double sn2, int dist_mode, double *dst, long ld) {
+  if (nrows <= 0 || ncols <= 0) return GPAK_OK;
+  if (nrows % GPAK_TILE || ncols % 64) return GPAK_EINVAL;
+  KernParams kp = make_kp(expans, bias, dist_mode, nullptr);
+  DevPoints P = as_points(u, cap, n, row0), Q = as_points(u, cap, n, col0);
+  // the diagonal of the matrix is where (row0 + a) == (col0 + c): col_off = col0 - row0 in the fill's own coordinates
+  gpak_launch_fill((hipStream_t)stream, P, Q, nrows, ncols, kp, 1.0 / sn2, 1.0, 1.0, row0 == col0 ? 1 : 0, dst, ld, nullptr,
+                   col0 - row0);
+  return status();
+}
+
+int gpak_dev_solve_rows(void *stream, double *P, long ld, int nrows, int W, const double *Lbb, long ldl,
+                        const double *inv) {
+  if (nrows <= 0) return GPAK_OK;
+  if (nrows % GPAK_TILE || W <= 0 || W % GPAK_TILE || W > 512) return GPAK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int mt = nrows / GPAK_TILE;
+  for (int s = 0; s < W / GPAK_TILE; s++) {
+    double *Ps = P + (size_t)s * GPAK_TILE * ld;
+    // P_s := P_s inv(D_s)^T: an A B^T product with B = the FIRST image of the block's pair (D_s^-1), as in gpak_factor_panel
+    gpak_launch_gemm_nt(st, mt, 1, GPAK_TILE, 1.0, Ps, ld, inv + (size_t)s * 2 * GPAK_TILE * GPAK_TILE, GPAK_TILE, 0.0, Ps,
+                        ld, 0, 0, false, false);
+    const int nct = W / GPAK_TILE - (s + 1);
+    if (nct > 0)   // P[:, s+1..] -= P_s Lbb[s+1.., s]^T
+      gpak_launch_gemm_nt(st, mt, nct, GPAK_TILE, -1.0, Ps, ld, Lbb + (size_t)(s + 1) * GPAK_TILE + (size_t)s * GPAK_TILE * ldl,
+                          ldl, 1.0, P + (size_t)(s + 1) * GPAK_TILE * ld, ld, 0, 0, false, false);
+  }
+  return status();
+}
+
+int gpak_dev_update_rect(void *stream, const double *A, long lda, const double *B, long ldb, int K, double *C, long ldc,
+                         int mrows, int ncols, int diag_first) {
+  if (mrows <= 0 || ncols <= 0) return GPAK_OK;
+  if (mrows % GPAK_TILE || ncols % GPAK_TILE || K % GPAK_TILE) return GPAK_EINVAL;
+  // diag_first: tile (ti, tj) of the leading square is skipped when ti < tj (row_block0 = col_block0 = 0); otherwise
+  // every tile takes part
+  gpak_launch_gemm_nt((hipStream_t)stream, mrows / GPAK_TILE, ncols / GPAK_TILE, K, -1.0, A, lda, B, ldb, 1.0, C, ldc, 0, 0,
+                      diag_first != 0, true);
+  return status();
+}
+
+int gpak_dev_gemv_n_add(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y) {
+  if (nrows <= 0 || W <= 0) return GPAK_OK;
+  if (W > 512) return GPAK_EINVAL;
+  hipLaunchKernelGGL(gpak_gemv_n_add_f64, dim3((nrows + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, ld, nrows, W, x, y);
+  return status();
+}
+
+int gpak_dev_gemv_t(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y) {
+  if (W <= 0) return GPAK_OK;
+  hipLaunchKernelGGL(gpak_gemv_t_f64, dim3(W), dim3(256), 0, (hipStream_t)stream, A, ld, nrows > 0 ? nrows : 0, x, y);
+  return status();
+}
+
+int gpak_dev_vec_axpy(void *stream, int n, double a, const double *x, double *y) {
+  gpak_launch_axpy((hipStream_t)stream, n, a, x, y);
   return status();
 }
 

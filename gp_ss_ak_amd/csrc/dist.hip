@@ -131,6 +131,7 @@ int he_event_elapsed(void *, void *e0, void *e1, double *ms) {
 }
 
 void fill_hip_engine(gpak_dist_engine &e, HipEngineState *st) {
+  memset(&e, 0, sizeof(e));
   e.self = st;
   e.alloc = he_alloc; e.release = he_release; e.upload = he_upload; e.download = he_download;
   e.zero = he_zero; e.copy = he_copy;
@@ -974,3 +975,5 @@ int gpak_dist_factor_view_get(gpak_dist *h, gpak_dist_factor_view *out) {
   return GPAK_OK;
 }
 double gpak_dist_grad_ms(const gpak_dist *h) { return h ? h->grad_ms : 0.0; }
+
+#include "grid.inc"

@@ -79,6 +79,8 @@ struct GpakTuning {
   int f32_tile = 128;          // GPAK_F32_TILE      wave tile rows of the plain fp32 kernel: 128 / 64
   int fs_levels[8] = {128, 512, 2048, 8192, 0, 0, 0, 0};   // GPAK_FS_LEVELS_F32  ladder of the fp32 substitution
   int pred_batch = 0;          // GPAK_PRED_BATCH    test points per batch (0: 16384 fp64, 65536 fp32)
+  int pred_ld_skew = 1;        // GPAK_PRED_LD_SKEW  leading dimensions of the test-major batch and of the fp32 factor image
+                               //                    are skewed by this many 256-byte units (0: powers of two, as in round 2)
 };
 const GpakTuning &gpak_tuning();
 
@@ -138,6 +140,7 @@ struct gpak_ctx {
   size_t wt_elems = 0;
   // fp32 prediction (ctx created with GPAK_F32): fp32 images of L and of the inverse blocks
   float *dLf = nullptr, *dInvf = nullptr;
+  long ldLf = 0;             // leading dimension of dLf (Np + skew)
   bool lf_ok = false;
 
   // gradient buffers (allocated on the first gpak_grad)

@@ -67,7 +67,8 @@ static int ensure_predict_bufs(gpak_ctx *ctx, int cap, bool want_var) {
   }
   int rc = gpak_alloc_points(ctx, ctx->Upred, ctx->Np);
   if (rc) return rc;
-  size_t need = want_var ? (size_t)ctx->pred_cap * ctx->Np : 0;
+  // (pred_cap + skew) x Np: the batch is stored with a skewed leading dimension (gpak_predict_impl)
+  size_t need = want_var ? ((size_t)ctx->pred_cap + 64 * (size_t)std::max(0, ctx->tune.pred_ld_skew)) * ctx->Np : 0;
   if (need > ctx->wt_elems) {
     if (ctx->dWt) hipFree(ctx->dWt);
     ctx->dWt = nullptr; ctx->wt_elems = 0;
@@ -113,14 +114,17 @@ static void forward_subst_batch(gpak_ctx *ctx, double *Wt, long ldw, int mbp) {
 static int ensure_f32_factor(gpak_ctx *ctx) {
   if (ctx->lf_ok) return GPAK_OK;
   const int Np = ctx->Np, T = Np / PB;
+  // k-columns 128 KiB apart (Np = 32768 floats) would all fall on the same L2 channel / HBM bank group: skew the
+  // leading dimension by 256 B like the fp64 matrix (gpak_set_train)
+  ctx->ldLf = Np + 64L * std::max(0, ctx->tune.pred_ld_skew);
   if (!ctx->dLf) {
-    if (hipMalloc(&ctx->dLf, sizeof(float) * (size_t)Np * Np) != hipSuccess ||
+    if (hipMalloc(&ctx->dLf, sizeof(float) * (size_t)ctx->ldLf * Np) != hipSuccess ||
         hipMalloc(&ctx->dInvf, sizeof(float) * (size_t)T * 2 * PB * PB) != hipSuccess) {
       ctx->err = "device allocation failed for the fp32 factor image";
       return GPAK_ENOMEM;
     }
   }
-  gpak_launch_lower_to_f32(ctx->stream, ctx->dM, ctx->ld, Np, ctx->dLf, Np);
+  gpak_launch_lower_to_f32(ctx->stream, ctx->dM, ctx->ld, Np, ctx->dLf, ctx->ldLf);
   gpak_launch_vec_to_f32(ctx->stream, ctx->dInv, (size_t)T * 2 * PB * PB, ctx->dInvf);
   ctx->lf_ok = true;
   return GPAK_OK;
@@ -136,7 +140,6 @@ static int ensure_f32_factor(gpak_ctx *ctx) {
 // summed in fp64, gemm_f32.hip): 7.4e-7 whatever the ladder, which is then chosen for speed alone.
 // GPAK_FS_LEVELS_F32="128,512" restores the two-level scheme (A/B runs).
 static void fs_block_f32(gpak_ctx *ctx, float *Wt, long ldw, int mt, int J0, int W, const std::vector<int> &lv, int k) {
-  const int Np = ctx->Np;
   hipStream_t st = ctx->stream;
   if (k == 0) {   // W == 128: product with the explicit inverse of the diagonal block
     const float *inv = ctx->dInvf + (size_t)(J0 / PB) * 2 * PB * PB;
@@ -150,7 +153,7 @@ static void fs_block_f32(gpak_ctx *ctx, float *Wt, long ldw, int mt, int J0, int
     fs_block_f32(ctx, Wt, ldw, mt, j0, w, lv, k - 1);
     const int nrest = (J0 + W - j0 - w) / PB;
     if (nrest > 0)
-      gpak_launch_gemm_nt_f32(st, mt, nrest, w, -1.f, Wt + (size_t)j0 * ldw, ldw, ctx->dLf + (j0 + w) + (size_t)j0 * Np, Np,
+      gpak_launch_gemm_nt_f32(st, mt, nrest, w, -1.f, Wt + (size_t)j0 * ldw, ldw, ctx->dLf + (j0 + w) + (size_t)j0 * ctx->ldLf, ctx->ldLf,
                               1.f, Wt + (size_t)(j0 + w) * ldw, ldw);
   }
 }
@@ -213,7 +216,9 @@ int gpak_predict_impl(gpak_ctx *ctx, const double *Xte, long M, double *mean, do
     gpak_launch_kmatvec(st, ctx->Upred, 0, N, ctx->dAlpha, ctx->Tq, kp, ctx->dPart, splits, dMean);
     GPAK_HIP(hipMemcpyAsync(mean + b0, dMean, sizeof(double) * mb, hipMemcpyDeviceToHost, st));
     if (var) {
-      const long ldw = cap;
+      // test-major batch, k-columns `ldw` apart: a power-of-two stride (cap = 65536 floats = 256 KiB) puts every k-column
+      // of a row tile on the same L2 channel -- skewed by 256 B like the fp64 matrix
+      const long ldw = cap + (f32 ? 64L : 32L) * std::max(0, ctx->tune.pred_ld_skew);
       int vs = std::max(1, std::min(64, Np / 512));
       int cps = (Np + vs - 1) / vs;
       if (f32) {

@@ -59,6 +59,14 @@ ENGINE_FIELDS = [
     ("grad_binv_rows", _F(C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), _vp)),
     ("grad_pairs_rows", _F(C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                            _dp, C.c_double, C.c_double, C.c_int, _vp, _vp)),
+    # the row-block x column-block layout (gpak_grid_*)
+    ("fill_rect", _F(C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_double,
+                     C.c_int, _vp, C.c_long)),
+    ("solve_rows", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, _vp, C.c_long, _vp)),
+    ("update_rect", _F(C.c_int, _vp, _vp, C.c_long, _vp, C.c_long, C.c_int, _vp, C.c_long, C.c_int, C.c_int, C.c_int)),
+    ("gemv_n_add", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp)),
+    ("gemv_t", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp)),
+    ("vec_axpy", _F(C.c_int, _vp, C.c_int, C.c_double, _vp, _vp)),
 ]
 
 
@@ -72,6 +80,10 @@ class Transport(C.Structure):
         ("bcast", _F(C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_int)),
         ("allreduce_sum", _F(C.c_int, _vp, _vp, _vp, C.c_size_t)),
         ("allreduce_min_int", _F(C.c_int, _vp, _vp, _vp, C.c_size_t)),
+        # sub-groups of a Pr x Pc grid (NULL: 1-D layouts only)
+        ("grid_setup", _F(C.c_int, _vp, C.c_int, C.c_int)),
+        ("bcast_group", _F(C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int)),
+        ("allreduce_sum_group", _F(C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_int)),
     ]
 
 
@@ -88,6 +100,8 @@ DIST_SYMBOLS = ["gpak_dist_create", "gpak_dist_destroy", "gpak_dist_last_error",
                 "gpak_dist_init_rccl", "gpak_dist_selfcheck", "gpak_dist_set_train", "gpak_dist_set_params",
                 "gpak_dist_nlz", "gpak_dist_nlz_terms", "gpak_dist_grad", "gpak_dist_get_alpha", "gpak_dist_get_stats",
                 "gpak_dist_failed_column", "gpak_group_rank_stats", "gpak_create_multi_with_engines",
+                "gpak_grid_create", "gpak_grid_destroy", "gpak_grid_last_error", "gpak_grid_init_rccl", "gpak_grid_set_train",
+                "gpak_grid_set_params", "gpak_grid_nlz", "gpak_grid_nlz_terms", "gpak_grid_get_alpha", "gpak_grid_get_stats",
                 "gpak_dev_vec_scale", "gpak_dev_vec_sum"]
 
 
@@ -113,6 +127,19 @@ def _load():
     lib.gpak_dist_get_stats.argtypes = [_vp, C.POINTER(Stats)]
     lib.gpak_dist_failed_column.argtypes = [_vp]
     lib.gpak_group_rank_stats.argtypes = [_vp, C.c_int, C.POINTER(Stats)]
+    lib.gpak_grid_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Engine),
+                                     C.POINTER(Transport)]
+    lib.gpak_grid_destroy.argtypes = [_vp]
+    lib.gpak_grid_destroy.restype = None
+    lib.gpak_grid_last_error.argtypes = [_vp]
+    lib.gpak_grid_last_error.restype = C.c_char_p
+    lib.gpak_grid_init_rccl.argtypes = [_vp, C.c_char_p]
+    lib.gpak_grid_set_train.argtypes = [_vp, _dp, _dp, C.c_int, C.c_int, C.c_int]
+    lib.gpak_grid_set_params.argtypes = [_vp, _dp, C.c_double, C.c_double, C.c_int]
+    lib.gpak_grid_nlz.argtypes = [_vp, _dp]
+    lib.gpak_grid_nlz_terms.argtypes = [_vp, _dp, _dp, _dp]
+    lib.gpak_grid_get_alpha.argtypes = [_vp, _dp]
+    lib.gpak_grid_get_stats.argtypes = [_vp, C.POINTER(Stats)]
     return lib
 
 
@@ -154,7 +181,38 @@ class StagedTransport:
         def ar_min(_self, st, buf, count):
             return stage(st, buf, count, torch.int32, lambda t: dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group))
 
-        self._keep = (Transport._fields_[1][1](bcast), Transport._fields_[2][1](ar_sum), Transport._fields_[3][1](ar_min))
+        # sub-groups of a Pr x Pc grid (rank = pr + Pr * pc): torch.distributed groups made on demand, the same way on
+        # every rank (new_group is collective over the world)
+        self.groups = {}
+
+        def grid_setup(_self, Pr, Pc):
+            world = dist.get_world_size(group)
+            rank = dist.get_rank(group)
+            if Pr * Pc != world:
+                return 2
+            pr, pc = rank % Pr, rank // Pr
+            for r in range(Pr):
+                members = [r + Pr * c for c in range(Pc)]
+                g = dist.new_group(members)
+                if r == pr:
+                    self.groups[1] = (g, members)
+            for c in range(Pc):
+                members = [r + Pr * c for r in range(Pr)]
+                g = dist.new_group(members)
+                if c == pc:
+                    self.groups[2] = (g, members)
+            return 0
+
+        def bcast_g(_self, st, buf, count, root, grp):
+            g, members = self.groups[grp]
+            return stage(st, buf, count, torch.float64, lambda t: dist.broadcast(t, src=members[root], group=g))
+
+        def ar_sum_g(_self, st, buf, count, grp):
+            g, _ = self.groups[grp]
+            return stage(st, buf, count, torch.float64, lambda t: dist.all_reduce(t, group=g))
+
+        F = Transport._fields_
+        self._keep = (F[1][1](bcast), F[2][1](ar_sum), F[3][1](ar_min), F[4][1](grid_setup), F[5][1](bcast_g), F[6][1](ar_sum_g))
         self.table = Transport(None, *self._keep)
 
 
@@ -241,6 +299,72 @@ class DistRank:
     def stats(self):
         s = Stats()
         self._check(self._lib.gpak_dist_get_stats(self._h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in s._fields_}
+
+
+class GridRank:
+    """One rank of the row-block x column-block layout (gpak_grid_* of include/gpak_dist.h, csrc/grid.inc) on a Pr x Pc
+    process grid, rank = pr + Pr * pc.  engine / transport: None = built-in HIP engine / built-in RCCL transport (world
+    communicator + ncclCommSplit row and column communicators)."""
+
+    def __init__(self, rank, world, Pr, Pc, device=0, engine=None, transport=None, rccl_id=None):
+        self._lib = _load()
+        self._engine, self._transport = engine, transport
+        h = _vp()
+        rc = self._lib.gpak_grid_create(C.byref(h), rank, world, Pr, Pc, device,
+                                        C.byref(engine.table) if engine is not None else None,
+                                        C.byref(transport.table) if transport is not None else None)
+        if rc != 0:
+            raise DistError(rc, "gpak_grid_create failed (Pr * Pc != world, Pr == 1, an engine / transport without the "
+                                "2-D entries, or no gfx950 device: there is no CPU fallback)")
+        self._h = h
+        self.rank, self.world, self.Pr, self.Pc = rank, world, Pr, Pc
+        if transport is None:
+            if rccl_id is None:
+                raise ValueError("the RCCL transport needs the unique id made on rank 0 (DistRank.rccl_unique_id())")
+            self._check(self._lib.gpak_grid_init_rccl(self._h, rccl_id))
+
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise DistError(rc, self._lib.gpak_grid_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpak_grid_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_train(self, X, y, nb=512):
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+        self.N = X.shape[0]
+        self._check(self._lib.gpak_grid_set_train(self._h, X.ctypes.data_as(_dp), y.ctypes.data_as(_dp), X.shape[0],
+                                                  X.shape[1], int(nb)))
+
+    def set_params(self, expans, bias, sn2, dist_mode=1):
+        e = np.ascontiguousarray(expans, dtype=np.float64)
+        self._check(self._lib.gpak_grid_set_params(self._h, e.ctypes.data_as(_dp), float(bias), float(sn2), int(dist_mode)))
+
+    def nlz(self):
+        v = C.c_double()
+        rc = self._check(self._lib.gpak_grid_nlz(self._h, C.byref(v)), allow=(1,))
+        return v.value if rc == 0 else math.nan
+
+    def nlz_terms(self):
+        q, s, l = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.gpak_grid_nlz_terms(self._h, C.byref(q), C.byref(s), C.byref(l)))
+        return q.value, s.value, l.value
+
+    def get_alpha(self):
+        a = np.zeros(self.N)
+        self._check(self._lib.gpak_grid_get_alpha(self._h, a.ctypes.data_as(_dp)))
+        return a
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.gpak_grid_get_stats(self._h, C.byref(s)))
         return {name: getattr(s, name) for name, _ in s._fields_}
 
 
@@ -373,6 +497,31 @@ def bench(args):
         # north_star's scaling curve is quoted at N=65536 (BASELINE.json configs[3]): a short run of that size rides
         # along as a sub-object; it needs 32 GiB / P + 17 GB per GPU
         extra = _one_size(args, 65536, dist, rank, world, local, make_rank, max(1, min(args.steps, 3)), 1, bench_mod)
+    # the row-block x column-block layouts of the same world size (north_star's 2-D sharding, csrc/grid.inc) ride along:
+    # a short run per grid, so that one line holds both layouts' step time and bytes received per rank
+    grids = []
+    want = getattr(args, "grid", "auto")
+    if want != "none":
+        shapes = ([tuple(int(v) for v in want.split("x"))] if want not in ("auto", "") else
+                  [(pr, world // pr) for pr in (2, 4, 8) if world % pr == 0 and pr <= world])
+        for (gr, gc) in shapes:
+            if gr * gc != world or gr < 2:
+                continue
+
+            def make_grid(gr=gr, gc=gc):
+                if staged:
+                    return GridRank(rank, world, gr, gc, device=local, transport=StagedTransport())
+                ids = [DistRank.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                return GridRank(rank, world, gr, gc, device=local, rccl_id=ids[0])
+            ok, why = 1, ""
+            try:
+                g_res = _one_size(args, args.n, dist, rank, world, local, make_grid, max(1, min(args.steps, 3)), 1, bench_mod)
+            except Exception as e:   # noqa: BLE001 -- a layout that cannot start is reported, not fatal
+                ok, why, g_res = 0, f"{type(e).__name__}: {e}", None
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            grids.append(((gr, gc), g_res if int(flag.item()) else None, why))
     out = None
     if rank == 0:
         def line(r, steps):
@@ -413,5 +562,20 @@ def bench(args):
         out["roofline"]["frac"] = a / bench_mod.PEAK_F64_MFMA_TFLOPS if a else None
         if extra is not None:
             out["n65536"] = line(extra, max(1, min(args.steps, 3)))
+        if grids:
+            out["grid_layouts"] = []
+            for (gr, gc), g_res, why in grids:
+                if g_res is None:
+                    out["grid_layouts"].append({"grid": f"{gr}x{gc}", "error": why or "failed on another rank"})
+                    continue
+                gl = line(g_res, max(1, min(args.steps, 3)))
+                out["grid_layouts"].append({
+                    "grid": f"{gr}x{gc}", "layout": "row-block x column-block, block (i, j) on rank (i % Pr) + Pr * (j % Pc)",
+                    "steps_per_s": gl["steps_per_s"], "ms_per_step": gl["ms_per_step"], "nlz": gl["nlz"],
+                    "bytes_received_per_rank_per_step": [p["bytes_broadcast"] for p in gl["phases_ms_per_rank"]],
+                    "model_bytes_per_rank": 8.0 * g_res["stats"]["n_padded"] ** 2 / 2 * (1.0 / gr + 1.0 / gc),
+                    "phases_ms_per_rank": gl["phases_ms_per_rank"]})
+            out["grid_layouts_note"] = ("1-D block-column-cyclic (the headline value above) receives (P-1)/P * N^2/2 * 8 B per "
+                                        "rank and step: " + str(8.0 * res["stats"]["n_padded"] ** 2 / 2 * (world - 1) / world))
     dist.destroy_process_group()
     return out

@@ -110,6 +110,24 @@ int gpak_dev_grad_finish(const double *expans, double bias, double sn2, int n, c
 /* host only: the constants of the pair pass, M36 = M_p (6 x {00,01,02,11,12,22}), m2_18 = 2 * column sums of M_p */
 int gpak_dev_grad_consts(const double *expans, double *M36, double *m2_18);
 
+/* ---- pieces of the row-block x column-block layout (gpak_grid_*, include/gpak_dist.h): rectangular parts of a rank's
+ * LOCAL storage; no global row addressing.  Semantics: the engine entries of the same names in gpak_dist.h.
+ * gpak_dev_fill_rect: ExpAns + Bias piece of B = I + K/sn2 (the fill of HybKerns::computeK + ldB2_exact's scaling,
+ *   Kernel.cpp:856-882, 362-367, GP_Utils.cpp:898-902); nrows a multiple of 128, ncols of 64.
+ * gpak_dev_solve_rows: P := P Lbb^-T in 128-column steps (product with the inverted diagonal block, K = 128 update of
+ *   the columns to the right), W <= 512.
+ * gpak_dev_update_rect: the trailing update C -= A B^T of one block column of local blocks (MFMA GEMM).
+ * gpak_dev_gemv_n_add / gpak_dev_gemv_t: the two matrix-vector products of the distributed triangular solves. */
+int gpak_dev_fill_rect(void *stream, const double *u, int cap, int n, int row0, int nrows, int col0, int ncols,
+                       const double *expans, double bias, double sn2, int dist_mode, double *dst, long ld);
+int gpak_dev_solve_rows(void *stream, double *P, long ld, int nrows, int W, const double *Lbb, long ldl,
+                        const double *inv);
+int gpak_dev_update_rect(void *stream, const double *A, long lda, const double *B, long ldb, int K, double *C, long ldc,
+                         int mrows, int ncols, int diag_first);
+int gpak_dev_gemv_n_add(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y);
+int gpak_dev_gemv_t(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y);
+int gpak_dev_vec_axpy(void *stream, int n, double a, const double *x, double *y);
+
 /* A HIP stream that may not use the first skip_cus compute units (hipExtStreamCreateWithCUMask): the bulk
  * updates of a rank run there, so that the serial panel chain (potrf128, the small panel products) always finds
  * idle CUs beside them.  skip_cus = 0 gives an ordinary non-blocking stream.  Wrap it for torch with

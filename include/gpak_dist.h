@@ -86,6 +86,21 @@ typedef struct gpak_dist_engine {
   int (*grad_pairs_rows)(void *stream, const double *u, int cap, const double *x_soa, int xs, int n, int Np,
                          const double *y, const double *f, const double *alpha, const double *binv, int P, int a,
                          const double *expans, double bias, double sn2, int dist_mode, double *part, double *out);
+  /* ---- the row-block x column-block layout (gpak_grid_*): rectangular pieces of a rank's LOCAL storage ---- */
+  /* dst[a + c*ld] = (K(row0 + a, col0 + c) / sn2 + [row0 + a == col0 + c]) for a < nrows, c < ncols (global indices into
+   * the transformed points u; rows / columns beyond n are zero with a unit diagonal); a piece that holds part of the
+   * diagonal (row0 == col0) is filled in its lower 128-tiles only */
+  int (*fill_rect)(void *stream, const double *u, int cap, int n, int row0, int nrows, int col0, int ncols,
+                   const double *expans, double bias, double sn2, int dist_mode, double *dst, long ld);
+  /* P (nrows x W, ld) := P * Lbb^-T, Lbb the W x W lower factor (ldl) with its inverted 128-blocks `inv` */
+  int (*solve_rows)(void *stream, double *P, long ld, int nrows, int W, const double *Lbb, long ldl, const double *inv);
+  /* C (mrows x ncols, ldc) -= A (mrows x K, lda) * B (ncols x K, ldb)^T; diag_first: the leading ncols x ncols square
+   * of C lies on the matrix diagonal -- only its lower 128-tiles are touched */
+  int (*update_rect)(void *stream, const double *A, long lda, const double *B, long ldb, int K, double *C, long ldc,
+                     int mrows, int ncols, int diag_first);
+  int (*gemv_n_add)(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y); /* y += A x   */
+  int (*gemv_t)(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y);     /* y  = A^T x */
+  int (*vec_axpy)(void *stream, int n, double a, const double *x, double *y);                              /* y += a x   */
 } gpak_dist_engine;
 
 /* Collectives on device buffers, enqueued on `stream` (an engine stream) in call order; every rank calls them in
@@ -95,7 +110,15 @@ typedef struct gpak_dist_transport {
   int (*bcast)(void *self, void *stream, double *buf, size_t count, int root);
   int (*allreduce_sum)(void *self, void *stream, double *buf, size_t count);
   int (*allreduce_min_int)(void *self, void *stream, int *buf, size_t count);
+  /* Sub-groups of a Pr x Pc process grid, rank = pr + Pr * pc.  group 1: my process ROW (the Pc ranks with my pr;
+   * member index = pc), group 2: my process COLUMN (the Pr ranks with my pc; member index = pr); root is a member
+   * index.  NULL entries: the transport serves 1-D layouts only (gpak_grid_create refuses it for Pr, Pc > 1). */
+  int (*grid_setup)(void *self, int Pr, int Pc);
+  int (*bcast_group)(void *self, void *stream, double *buf, size_t count, int root, int group);
+  int (*allreduce_sum_group)(void *self, void *stream, double *buf, size_t count, int group);
 } gpak_dist_transport;
+#define GPAK_GROUP_ROW 1
+#define GPAK_GROUP_COL 2
 
 /* rank / world: this rank and the number of ranks; device: HIP ordinal of the built-in engine (ignored with a
  * callback engine).  engine / transport: NULL = built-in HIP engine / built-in RCCL transport (the callback
@@ -160,6 +183,31 @@ typedef struct {
 int gpak_dist_get_stats(gpak_dist *h, gpak_dist_stats *out);
 /* the same for rank `rank` of a multi-GPU context made by gpak_create_multi (gpak.h); GPAK_EINVAL for a one-GPU context */
 int gpak_group_rank_stats(struct gpak_ctx *ctx, int rank, gpak_dist_stats *out);
+
+/* ---- row-block x column-block layout (north_star's 2-D sharding): csrc/grid.inc -------------------------------------
+ * B = I + K/sn2 in nb x nb blocks, block (i, j), i >= j, on rank (i % Pr) + Pr * (j % Pc) of a Pr x Pc grid.
+ * Step b: the owner of the diagonal block factors it (LDS-resident 128-blocks) and broadcasts it with its inverted
+ * 128-blocks DOWN its process column; the ranks of that column solve their rows of panel b and broadcast them ALONG
+ * their process rows; the row pieces P_j that a rank needs transposed (its own block columns j) come from rank
+ * (j % Pr) of its process column: one packed broadcast per root.  A rank therefore receives N^2/2 * 8 B * (1/Pr + 1/Pc)
+ * per factorisation instead of the 1-D layout's (P-1)/P * N^2/2 * 8 B, and keeps only its own blocks: N^2 / (2 P)
+ * doubles (+ two panel buffers).  The triangular solves are distributed (per block: a group all-reduce of the partial
+ * sums, the owner's 512-column solve, a world broadcast of the piece).  logLikelihood / alpha only: the gradient and
+ * prediction need a whole factor per rank and stay on the 1-D layout (gpak_dist_*).  Same engine / transport tables;
+ * world = Pr * Pc; Pr = 1 is refused (that IS the 1-D layout: use gpak_dist_create). */
+typedef struct gpak_grid gpak_grid;
+int gpak_grid_create(gpak_grid **out, int rank, int world, int Pr, int Pc, int device, const gpak_dist_engine *engine,
+                     const gpak_dist_transport *transport);
+void gpak_grid_destroy(gpak_grid *h);
+const char *gpak_grid_last_error(const gpak_grid *h);
+/* RCCL: world communicator from the unique id, then ncclCommSplit into the row and the column communicator */
+int gpak_grid_init_rccl(gpak_grid *h, const char *id);
+int gpak_grid_set_train(gpak_grid *h, const double *X, const double *y, int N, int d, int nb);
+int gpak_grid_set_params(gpak_grid *h, const double *expans, double bias, double sn2, int dist_mode);
+int gpak_grid_nlz(gpak_grid *h, double *nlz);
+int gpak_grid_nlz_terms(gpak_grid *h, double *quad, double *sumlp, double *logdet);
+int gpak_grid_get_alpha(gpak_grid *h, double *alpha_host);
+int gpak_grid_get_stats(gpak_grid *h, gpak_dist_stats *out);   /* bytes_broadcast = what THIS rank received */
 
 /* TEST entry point: a gpak_create_multi group (one host thread per rank, in-process transport, the gpak_ctx surface of
  * logLikelihood / alpha / gradient; no prediction: there are no device replicas) over n_ranks CALLER-SUPPLIED engines.

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--grad", type=int, default=0)
     ap.add_argument("--corrupt", type=int, default=0)
+    ap.add_argument("--grid", default="", help="PrxPc: the row-block x column-block layout (gpak_grid_*)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -31,7 +32,15 @@ def main():
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
     from gp_ss_ak_amd import dist as gd, synth
     eng = None
-    if a.engine == "hip":
+    grid = tuple(int(v) for v in a.grid.split("x")) if a.grid else None
+    if grid is not None:
+        if a.engine == "hip":
+            gp = gd.GridRank(a.rank, a.world, grid[0], grid[1], device=0, transport=gd.StagedTransport())
+        else:
+            from np_dist_engine import GlooTransport, NumpyDistEngine
+            eng, tr = NumpyDistEngine(), GlooTransport()
+            gp = gd.GridRank(a.rank, a.world, grid[0], grid[1], engine=eng, transport=tr)
+    elif a.engine == "hip":
         # every rank on GPU 0: the built-in HIP engine with the collectives staged through gloo (RCCL refuses two
         # ranks on one device); world 1 uses the built-in RCCL transport (a no-op communicator-free path)
         tr = gd.StagedTransport() if a.world > 1 else None
@@ -55,7 +64,7 @@ def main():
     if nlz == nlz:
         q, s, l = gp.nlz_terms()
         res.update({"alpha": gp.get_alpha().tolist(), "logdet": l, "quad": q, "sumlp": s})
-        if a.grad:
+        if a.grad and grid is None:
             res["grad"] = gp.grad().tolist()
     if eng is not None:
         # schedule facts the tests assert: which stream every factor / update was issued on

@@ -68,8 +68,28 @@ class NumpyDistEngine:
             eng.fill_b(_t(u, 5 * cap), cap, n, Np, J, W, [expans[i] for i in range(8)], bias, sn2, mode, _t(blk, W * ld), ld)
 
         def factor_panel(st, blk, ld, Np, J, W, inv, info):
+            # rows J .. Np of the block column through a strided view: `blk` may be a VIRTUAL base (the grid layout passes
+            # block - J so that global row J is the block's first local row), which a reshape by ld cannot address
             self.calls.append(("factor", J, st))
-            eng.factor_panel(_t(blk, W * ld), ld, Np, J, W, _t(inv, W // TILE * 2 * TILE * TILE), _t(info, 1, np.int32))
+            import scipy.linalg as sl
+            M = _strided(int(blk) + 8 * J, Np - J, W, ld)
+            D = np.tril(M[:W, :])
+            D = D + np.tril(D, -1).T
+            infon = _arr(info, 1, np.int32)
+            try:
+                L = sl.cholesky(D, lower=True)
+            except sl.LinAlgError:
+                k = next(i for i in range(1, W + 1) if np.linalg.eigvalsh(D[:i, :i]).min() <= 0)
+                infon[0] = min(int(infon[0]), J + k)
+                L = np.eye(W)
+            M[:W, :] = L
+            if Np - J > W:
+                M[W:, :] = sl.solve_triangular(L, M[W:, :].T, lower=True).T
+            iv = inv_blocks(inv, W)
+            for k in range(W // TILE):
+                X = np.linalg.inv(L[k * TILE:(k + 1) * TILE, k * TILE:(k + 1) * TILE])
+                iv[k, 0] = X.T
+                iv[k, 1] = X
 
         def update_block(st, panel, ldp, prow0, W, blk, ld, Np, Jc, Wc):
             self.calls.append(("update_block", Jc, st))
@@ -116,7 +136,9 @@ class NumpyDistEngine:
             _strided(rinv, W, W, 512)[:] = np.linalg.inv(L).T
 
         def logdiag_block(st, blk, ld, J, W, N, out):
-            eng.logdiag_block(_t(blk, W * ld), ld, J, W, N, _t(out, 1))
+            nc = max(0, min(W, N - J))
+            M = _strided(int(blk) + 8 * J, W, W, ld)
+            _arr(out, 1)[0] = float(np.log(np.diag(M)[:nc]).sum()) if nc else 0.0
 
         def kmatvec(st, u, cap, n, i0, i1, w, expans, bias, mode, scratch, out):
             eng.kmatvec(_t(u, 5 * cap), cap, n, i0, i1, _t(w, cap), [expans[i] for i in range(8)], bias, mode, None,
@@ -212,6 +234,48 @@ class NumpyDistEngine:
                     acc[p] = (wgt * rm * di2).sum()
             _arr(out, 17)[:] = acc
 
+        # ---- the row-block x column-block layout (gpak_grid_*): rectangular pieces of LOCAL storage -------------
+        def fill_rect(st, u, cap, n, row0, nrows, col0, ncols, expans, bias, sn2, mode, dst, ld):
+            un = _arr(u, 5 * cap).reshape(5, cap)
+            D = _strided(dst, nrows, ncols, ld)
+            D[:] = 0.0
+            r1, c1 = min(n, row0 + nrows), min(n, col0 + ncols)
+            if r1 > row0 and c1 > col0:
+                D[:r1 - row0, :c1 - col0] = eng._kfun(un, slice(row0, r1), slice(col0, c1), [expans[i] for i in range(8)],
+                                                      bias, mode) / sn2
+            for a in range(nrows):
+                c = row0 + a - col0
+                if 0 <= c < ncols:
+                    D[a, c] += 1.0
+            if row0 == col0:                      # a diagonal piece: only its lower 128-tiles are defined
+                for tj in range(ncols // TILE):
+                    D[:tj * TILE, tj * TILE:(tj + 1) * TILE] = np.nan
+
+        def solve_rows(st, P, ld, nrows, W, Lbb, ldl, inv):
+            import scipy.linalg as sl
+            Pm = _strided(P, nrows, W, ld)
+            L = np.tril(_strided(Lbb, W, W, ldl))
+            Pm[:] = sl.solve_triangular(L, Pm.T, lower=True).T
+
+        def update_rect(st, A, lda, B, ldb, K, Cp, ldc, mrows, ncols, diag_first):
+            self.calls.append(("update_rect", ncols, st))
+            Am, Bm, Cm = _strided(A, mrows, K, lda), _strided(B, ncols, K, ldb), _strided(Cp, mrows, ncols, ldc)
+            upd = Am @ Bm.T
+            if diag_first:
+                for tj in range(ncols // TILE):
+                    upd[:tj * TILE, tj * TILE:(tj + 1) * TILE] = 0.0     # tiles strictly above the diagonal: untouched
+            Cm -= upd
+
+        def gemv_n_add(st, A, ld, nrows, W, x, y):
+            if nrows > 0:
+                _arr(y, nrows)[:] += _strided(A, nrows, W, ld) @ _arr(x, W)
+
+        def gemv_t(st, A, ld, nrows, W, x, y):
+            _arr(y, W)[:] = _strided(A, nrows, W, ld).T @ _arr(x, nrows) if nrows > 0 else 0.0
+
+        def vec_axpy(st, n, a, x, y):
+            _arr(y, n)[:] += a * _arr(x, n)
+
         def vec_scale(st, n, a, s, out):
             _arr(out, n)[:] = _arr(a, n) * s
 
@@ -228,7 +292,8 @@ class NumpyDistEngine:
             "trsv_bwd_packed": ok(trsv_bwd_packed), "diag_inverse": ok(diag_inverse), "logdiag_block": ok(logdiag_block),
             "kmatvec": ok(kmatvec), "nlz_terms": ok(nlz_terms), "pack": ok(pack), "vec_scale": ok(vec_scale),
             "vec_sum": ok(vec_sum), "grad_g_rows": ok(grad_g_rows), "grad_binv_rows": ok(grad_binv_rows),
-            "grad_pairs_rows": ok(grad_pairs_rows),
+            "grad_pairs_rows": ok(grad_pairs_rows), "fill_rect": ok(fill_rect), "solve_rows": ok(solve_rows),
+            "update_rect": ok(update_rect), "gemv_n_add": ok(gemv_n_add), "gemv_t": ok(gemv_t), "vec_axpy": ok(vec_axpy),
         }
         self._keep = {name: F[name](fn) for name, fn in impl.items()}
         self.table = gd.Engine(None, *[self._keep[name] for name, _ in gd.ENGINE_FIELDS[1:]])
@@ -261,6 +326,38 @@ class GlooTransport:
             dist.all_reduce(_t(buf, count, np.int32), op=dist.ReduceOp.MIN, group=group)
             return 0
 
+        self.groups = {}
+        self.group_bytes = 0
+
+        def grid_setup(_s, Pr, Pc):
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            if Pr * Pc != world:
+                return 2
+            pr, pc = rank % Pr, rank // Pr
+            for r in range(Pr):                                   # new_group is collective over the world
+                members = [r + Pr * c for c in range(Pc)]
+                g = dist.new_group(members)
+                if r == pr:
+                    self.groups[1] = (g, members)
+            for c in range(Pc):
+                members = [r + Pr * c for r in range(Pr)]
+                g = dist.new_group(members)
+                if c == pc:
+                    self.groups[2] = (g, members)
+            return 0
+
+        def bcast_g(_s, st, buf, count, root, grp):
+            g, members = self.groups[grp]
+            self.group_bytes += 8 * int(count)
+            dist.broadcast(_t(buf, count), src=members[root], group=g)
+            return 0
+
+        def ar_sum_g(_s, st, buf, count, grp):
+            g, _m = self.groups[grp]
+            dist.all_reduce(_t(buf, count), group=g)
+            return 0
+
         T = gd.Transport._fields_
-        self._keep = (T[1][1](bcast), T[2][1](ar_sum), T[3][1](ar_min))
+        self._keep = (T[1][1](bcast), T[2][1](ar_sum), T[3][1](ar_min), T[4][1](grid_setup), T[5][1](bcast_g),
+                      T[6][1](ar_sum_g))
         self.table = gd.Transport(None, *self._keep)

@@ -32,7 +32,7 @@ def free_port():
     return p
 
 
-def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0, corrupt=0, env=None):
+def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0, corrupt=0, env=None, grid=None):
     port = free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
@@ -43,6 +43,8 @@ def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=9
                    os.path.join(d, f"r{r}.json")]
             if sn2 is not None:
                 cmd += ["--sn2", str(sn2)]
+            if grid is not None:
+                cmd += ["--grid", f"{grid[0]}x{grid[1]}"]
             penv = dict(os.environ, OMP_NUM_THREADS="2", **(env or {}))
             procs.append(subprocess.Popen(cmd, env=penv, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
@@ -184,6 +186,55 @@ def test_cpp_schedule_hip_engine_plain_stream_fallback(orc):
     for r in res:
         assert r["stats"]["flags"] == 3
         assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+
+
+# ---- the row-block x column-block layout (gpak_grid_*, csrc/grid.inc) ----------------------------------------------
+@pytest.mark.parametrize("grid,n,nb", [((2, 2), 700, 128), ((2, 3), 1300, 128), ((3, 2), 1500, 256), ((2, 2), 600, 256),
+                                        ((2, 4), 1200, 128), ((4, 2), 1100, 128), ((2, 1), 500, 128), ((4, 1), 900, 128)])
+def test_grid_layout_over_gloo_matches_oracle(orc, grid, n, nb):
+    """north_star's 2-D sharding on a Pr x Pc process grid, the C++ schedule driven by the NumPy engine over gloo row /
+    column / world groups: nlZ, its three terms and alpha against the oracle, identical on every rank; what a rank
+    receives is the (1/Pr + 1/Pc) share of the panels, not all of them."""
+    world = grid[0] * grid[1]
+    res = run_world(world, n, nb, grid=grid, steps=2)
+    info, alpha = oracle_ref(orc, n)
+    for r in res:
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz), (r["rank"], r["nlz"], info.nlz)
+        assert abs(r["logdet"] - info.logdet) <= 1e-10 * abs(info.logdet)
+        assert abs(r["quad"] - info.quad) <= 1e-9 * abs(info.quad) and abs(r["sumlp"] - info.sumlp) <= 1e-9 * abs(info.sumlp)
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+        assert r["nlz"] == res[0]["nlz"]
+    # communication volume: a rank receives about (1/Pr + 1/Pc) of the lower triangle (its row pieces + its transposed
+    # pieces + the diagonal blocks of its process column), where the 1-D layout sends it (P-1)/P of the triangle --
+    # 2 x 2 is therefore WORSE than 1-D (1.0 vs 0.75), 2 x 4 / 4 x 2 better (0.75 vs 0.875): DESIGN.md section 5
+    Np = res[0]["stats"]["n_padded"]
+    whole = 8.0 * Np * (Np + nb) / 2
+    for r in res:
+        assert 0 < r["stats"]["bytes_broadcast"] <= 1.35 * whole * (1.0 / grid[0] + 1.0 / grid[1])
+    # the bulk updates went to the bulk stream (kind 0 -> 100), the look-ahead column to the panel stream (101)
+    streams = {st for op, _, st in res[0]["calls"] if op == "update_rect"}
+    assert streams <= {100, 101} and 100 in streams
+
+
+def test_grid_layout_chol_fail_and_expansion_mode(orc):
+    res = run_world(4, 500, 128, grid=(2, 2), sn2=-0.5)
+    assert all(r["nlz"] != r["nlz"] for r in res)
+    res = run_world(4, 500, 128, grid=(2, 2), mode=0)
+    info, alpha = oracle_ref(orc, 500, mode=0)
+    assert all(abs(r["nlz"] - info.nlz) <= 1e-6 * abs(info.nlz) for r in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,n,nb", [((2, 2), 3000, 512), ((2, 2), 1300, 256), ((3, 2), 5000, 512)])
+def test_grid_layout_hip_engine_matches_oracle(orc, grid, n, nb):
+    """The same on the HIP engine (gpak_dev_fill_rect / solve_rows / update_rect / gemv kernels), Pr x Pc ranks rehearsed on
+    this box's one GPU with the collectives staged through gloo."""
+    res = run_world(grid[0] * grid[1], n, nb, engine="hip", grid=grid, steps=2)
+    info, alpha = oracle_ref(orc, n)
+    for r in res:
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz), (r["rank"], r["nlz"], info.nlz)
+        assert abs(r["logdet"] - info.logdet) <= 1e-10 * abs(info.logdet)
         assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
 
 

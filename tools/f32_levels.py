@@ -19,16 +19,27 @@ for g in (g64, g32):
     g.set_train(X, y)
     g.set_params(E, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
 m64, v64 = g64.posteriorMeanVar(Xte)
-print(f"fp64: {g64.timing()['predict_ms']:.0f} ms, var range {v64.min():.4g} .. {v64.max():.4g}", flush=True)
+print(f"fp64 (skew 1): {g64.timing()['predict_ms']:.0f} ms, var range {v64.min():.4g} .. {v64.max():.4g}", flush=True)
+os.environ["GPAK_PRED_LD_SKEW"] = "0"
+gpak._lib.load().gpak_reload_tuning()
+g64b = gpak.Gpak(0)
+g64b.set_train(X, y)
+g64b.set_params(E, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
+g64b.posteriorMeanVar(Xte)
+print(f"fp64 (skew 0): {g64b.timing()['predict_ms']:.0f} ms", flush=True)
+g64b.close()
+del os.environ["GPAK_PRED_LD_SKEW"]
 VARIANTS = [
-    {"GPAK_FS_LEVELS_F32": "128,512"},
-    {"GPAK_FS_LEVELS_F32": "128,512", "GPAK_F32_TILE": "64"},
-    {"GPAK_FS_LEVELS_F32": "128,512", "GPAK_F32_ACC": "wide", "GPAK_F32_RSD": "4"},
-    {"GPAK_FS_LEVELS_F32": "128,512", "GPAK_F32_ACC": "wide", "GPAK_F32_RSD": "2"},
-    {"GPAK_FS_LEVELS_F32": "128,512", "GPAK_F32_ACC": "wide", "GPAK_F32_RSD": "8"},
-    {"GPAK_FS_LEVELS_F32": "128,512,2048", "GPAK_F32_ACC": "wide", "GPAK_F32_RSD": "4"},
-    {"GPAK_FS_LEVELS_F32": "128,512,2048,8192", "GPAK_F32_ACC": "wide", "GPAK_F32_RSD": "4"},
-    {"GPAK_FS_LEVELS_F32": "128,1024", "GPAK_F32_ACC": "wide", "GPAK_F32_RSD": "4"},
+    {},
+    {"GPAK_PRED_LD_SKEW": "0"},
+    {"GPAK_PRED_LD_SKEW": "2"},
+    {"GPAK_F32_ACC": "plain", "GPAK_FS_LEVELS_F32": "128,512"},
+    {"GPAK_F32_ACC": "plain", "GPAK_FS_LEVELS_F32": "128,512", "GPAK_PRED_LD_SKEW": "0"},
+    {"GPAK_FS_LEVELS_F32": "128,512,2048"},
+    {"GPAK_FS_LEVELS_F32": "128,512,4096"},
+    {"GPAK_FS_LEVELS_F32": "128,1024,8192"},
+    {"GPAK_PRED_BATCH": "32768"},
+    {"GPAK_PRED_BATCH": "131072"},
 ]
 KEYS = sorted({k for v in VARIANTS for k in v})
 for var in VARIANTS:
