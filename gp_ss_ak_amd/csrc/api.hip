@@ -57,6 +57,7 @@ static GpakTuning read_tuning_env() {
   if (const char *e = getenv("GPAK_LD_PAD")) t.ld_pad = atol(e) / 2 * 2;
   geti("GPAK_GEMM_SMALL", t.gemm_small);
   geti("GPAK_GEMM_SMALL_ROWS", t.gemm_small_rows);
+  geti("GPAK_SUPER_LR", t.super_lr);
   getb("GPAK_FILL_FAST", t.fill_fast);
   getb("GPAK_KMV_SYM", t.kmv_sym);
   if (const char *e = getenv("GPAK_F32_ACC")) t.f32_wide = strcmp(e, "plain") != 0;

@@ -50,25 +50,35 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
                                                                const double *B, long ldb, double beta, double *C,
                                                                long ldc, int rb0, int cb0, int lower_skip, int mt,
                                                                int nt, int k0_by_row, int cyc_P, int cyc_rank,
-                                                               int cyc_tpb, int cyc_lt0) {
+                                                               int cyc_tpb, int cyc_lt0, int super_lr) {
   int ti, tj;
   {
+    // super-tile = 2^super_lr rows x 2^(6 - super_lr) columns of tiles (64 workgroups: what one XCD keeps resident);
+    // 3 = 8 x 8, the default (4 x 16 and 16 x 4 measured in round 3: profiles/r03_supertile_shapes.txt)
+    const int lr = super_lr, lc = 6 - super_lr;
     const int b = blockIdx.x, q = b >> 3;
     const int slot = q & 63;
     const int ssel = (q >> 6) * 8 + (b & 7);
-    const int SR = (mt + 7) >> 3, SC = (nt + 7) >> 3;
+    const int SR = (mt + (1 << lr) - 1) >> lr, SC = (nt + (1 << lc) - 1) >> lc;
     int si, sj = 0;
-    if (lower_skip == 1) {   // 1: super-tiles of the lower triangle only; 2: all super-tiles, per-tile rule below
+    if (lower_skip == 1) {   // 1: super-tiles that touch the lower triangle only; 2: all super-tiles, per-tile rule below
       int rem = ssel;
-      while (sj < SC && rem >= SR - sj) { rem -= SR - sj; sj++; }
-      si = sj + rem;
+      int first = 0;
+      for (; sj < SC; sj++) {   // first super row of column sj whose last tile row reaches the diagonal: (sj << lc) >> lr
+        first = (sj << lc) >> lr;
+        const int cnt = SR - first;
+        if (cnt <= 0) { sj = SC; break; }
+        if (rem < cnt) break;
+        rem -= cnt;
+      }
+      si = first + rem;
     } else {
       sj = ssel / SR;
       si = ssel - sj * SR;
     }
     if (sj >= SC) return;
-    ti = si * 8 + (slot & 7);
-    tj = sj * 8 + (slot >> 3);
+    ti = (si << lr) + (slot & ((1 << lr) - 1));
+    tj = (sj << lc) + (slot >> lr);
     if (ti >= mt || tj >= nt) return;
     if (lower_skip && (rb0 + ti) < (cb0 + tj)) return;
   }
@@ -299,7 +309,7 @@ void gpak_launch_gemm_cyclic(hipStream_t st, int mt, int nt, int K, const double
   const long nsuper = (long)SR * SC;
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, -1.0, Pv, ldp, Pv, ldp, 1.0, Clocal, ldc,
-                     rt0, 0, 0, mt, nt, 0, P, rank, tpb, lt0);
+                     rt0, 0, 0, mt, nt, 0, P, rank, tpb, lt0, 3);
 }
 
 // C (mt x nt tiles) = alpha * A * B^T with the k-loop of tile row ti started at global row block ti*k0_mul + k0_add
@@ -313,17 +323,28 @@ void gpak_launch_gemm_nt_k0map(hipStream_t st, int mt, int nt, int K, double alp
   dim3 grid((unsigned)((nsuper + 7) / 8 * 8 * 64)), block(256);
   // lower_skip = 0 in the super-tile walk (every super-tile is visited); the per-tile rule is rb0 + ti < cb0 + tj
   hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, 0.0, C, ldc, 0,
-                     skip_shift, 2, mt, nt, 0, 0, 0, k0_mul, k0_add);
+                     skip_shift, 2, mt, nt, 0, 0, 0, k0_mul, k0_add, 3);
 }
 
 void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, const double *A, long lda,
                          const double *B, long ldb, double beta, double *C, long ldc, int row_block0,
                          int col_block0, bool lower_skip, bool trailing, bool k0_by_row) {
   if (mt <= 0 || nt <= 0) return;
-  const int SR = (mt + 7) / 8, SC = (nt + 7) / 8;
+  // super-tile shape: 8 x 8 unless the bulk trailing update was asked for another one (GpakTuning::super_lr)
+  int lr = 3;
+  if (trailing && lower_skip && row_block0 == col_block0) {
+    lr = gpak_tuning().super_lr;
+    if (lr < 1 || lr > 5) lr = 3;
+  }
+  const int lc = 6 - lr;
+  const int SR = (mt + (1 << lr) - 1) >> lr, SC = (nt + (1 << lc) - 1) >> lc;
   long nsuper = 0;
   if (lower_skip) {
-    for (int sj = 0; sj < SC && sj < SR; sj++) nsuper += SR - sj;
+    for (int sj = 0; sj < SC; sj++) {
+      const int cnt = SR - ((sj << lc) >> lr);
+      if (cnt <= 0) break;
+      nsuper += cnt;
+    }
   } else {
     nsuper = (long)SR * SC;
   }
@@ -358,10 +379,10 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
   }
   if (trailing)
     hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0, lr);
   else
     hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0);
+                       row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0, lr);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -71,6 +71,7 @@ struct GpakTuning {
   // kernel selection
   int gemm_small = 160;        // GPAK_GEMM_SMALL      tile grids up to this size take the latency kernel
   int gemm_small_rows = 16;    // GPAK_GEMM_SMALL_ROWS rows per workgroup of that kernel: 16 / 32 / 64
+  int super_lr = 3;            // GPAK_SUPER_LR      bulk update: super-tiles of 2^lr x 2^(6-lr) tiles per XCD (3 = 8 x 8)
   bool fill_fast = true;       // GPAK_FILL_FAST     table exp + in-line sqrt fill / Gram-matvec
   bool kmv_sym = true;         // GPAK_KMV_SYM       symmetric Gram-matvec from 32 macro blocks on
   // fp32 prediction (GPAK_F32 contexts)
