@@ -24,10 +24,11 @@ static KernParams make_kp(const double *expans, double bias, int mode, const dou
   gpak_build_siginv(expans, kp.term[0].A);
   kp.term[0].var2 = expans[6] * expans[6];
   kp.term[0].profile = GPAK_PROFILE_EXPSQRT;
-  for (int k = 0; k < 3; k++) kp.mu[k] = mu ? mu[k] : 0.0;
-  kp.d = 3;  // the distributed path handles 3-D inputs
+  for (int k = 0; k < 4; k++) kp.mu[k] = mu ? mu[k] : 0.0;
+  kp.term[0].a33 = expans[7];   // InversewidthR: the 4th column's own inverse width (Kernel.cpp:1421-1424)
+  kp.d = (mode & GPAK_DIST_D4) ? 4 : 3;
   kp.bias = bias;
-  kp.mode = mode;
+  kp.mode = mode & 0xF;
   return kp;
 }
 static int status() { return hipGetLastError() == hipSuccess ? GPAK_OK : GPAK_EHIP; }
@@ -85,7 +86,8 @@ int gpak_dev_pack(void *stream, const double *src, long ld, int row0, int nrows,
 
 int gpak_dev_transform(void *stream, const double *x, int xs, int n, int cap, const double *expans,
                        const double *mu, double *u) {
-  KernParams kp = make_kp(expans, 0.0, GPAK_DIST_DIRECT, mu);
+  // always four columns: a 3-D input set carries a zero 4th column (and mu[3] = 0), whose image is 0
+  KernParams kp = make_kp(expans, 0.0, GPAK_DIST_DIRECT | GPAK_DIST_D4, mu);
   DevPoints p = as_points(u, cap, n);
   gpak_launch_transform((hipStream_t)stream, x, xs, n, kp, p);
   return status();

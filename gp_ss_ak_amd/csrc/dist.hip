@@ -242,7 +242,8 @@ struct gpak_dist {
   int N = 0, Np = 0, nb = 512, nJ = 0, cap = 0;
   long ld = 0;
   std::vector<int> owned;
-  double xsum[3] = {0, 0, 0};
+  double xsum[4] = {0, 0, 0, 0};
+  int d = 3;                          // input columns: 3, or 4 with a rock-type column
   double *x_soa = nullptr, *y = nullptr, *u = nullptr, *local = nullptr, *scratch = nullptr, *small = nullptr;
   double *alpha = nullptr, *fwd_x = nullptr, *fwd_z = nullptr, *rhs = nullptr, *f = nullptr, *bwd_scratch = nullptr;
   double *ld_slots = nullptr;
@@ -275,6 +276,7 @@ struct gpak_dist {
   std::vector<Span> spans;
   bool profile = true;
 
+  int kmode() const { return mode | (d == 4 ? GPAK_DIST_D4 : 0); }   // what the kernel-evaluating engine calls get
   int width(int b) const { return std::min(nb, Np - b * nb); }
   int start(int b) const { return b * nb; }
   int owner(int b) const { return b % P; }
@@ -552,10 +554,11 @@ int gpak_dist_selfcheck(gpak_dist *h, int *flags_out) {
 
 int gpak_dist_set_train(gpak_dist *h, const double *X, const double *y, int N, int d, int nb) {
   if (!h || !X || !y || N <= 0) return GPAK_EINVAL;
-  if (d != 3) { h->err = "the distributed path handles 3-D inputs"; return GPAK_ENOTIMPL; }
+  if (d != 3 && d != 4) { h->err = "inputs must have 3 or 4 columns"; return GPAK_ENOTIMPL; }
   if (nb == 0) nb = 512;
   if (nb < GPAK_TILE || nb % GPAK_TILE || nb > 512) { h->err = "nb must be 128, 256, 384 or 512"; return GPAK_EINVAL; }
   set_device(h);
+  h->d = d;
   if (!h->checked) {
     int rc = gpak_dist_selfcheck(h, nullptr);
     if (rc) return rc;
@@ -572,7 +575,7 @@ int gpak_dist_set_train(gpak_dist *h, const double *X, const double *y, int N, i
   for (int b = 0; b < h->nJ; b++) if (h->owner(b) == h->rank) h->owned.push_back(b);
   const size_t Np = h->Np;
   auto dalloc = [&](size_t n) { return (double *)E.alloc(E.self, sizeof(double) * (n ? n : 1)); };
-  h->x_soa = dalloc(3 * Np); h->y = dalloc(Np); h->u = dalloc(5 * Np);
+  h->x_soa = dalloc(4 * Np); h->y = dalloc(Np); h->u = dalloc(5 * Np);   // four raw columns, the 4th zero for d = 3
   h->local = dalloc(std::max<size_t>(1, h->owned.size()) * nb * h->ld);
   h->scratch = dalloc(64 * Np); h->small = dalloc(16); h->alpha = dalloc(Np);
   h->fwd_x = dalloc(Np); h->fwd_z = dalloc(Np); h->rhs = dalloc(Np); h->f = dalloc(Np);
@@ -597,14 +600,15 @@ int gpak_dist_set_train(gpak_dist *h, const double *X, const double *y, int N, i
     ok = h->panels[b] && h->rinv[b] && h->invs[b];
   }
   if (!ok) { h->err = "device allocation failed for the distributed training set"; release_problem(h); return GPAK_ENOMEM; }
-  std::vector<double> xs(3 * Np, 0.0), yp(Np, 0.0);
-  for (int k = 0; k < 3; k++) {
+  std::vector<double> xs(4 * Np, 0.0), yp(Np, 0.0);
+  h->xsum[3] = 0.0;
+  for (int k = 0; k < d; k++) {
     double s = 0.0;
     for (int i = 0; i < N; i++) { xs[k * Np + i] = X[i + (size_t)k * N]; s += X[i + (size_t)k * N]; }
     h->xsum[k] = s;
   }
   for (int i = 0; i < N; i++) yp[i] = y[i];
-  DCHK(E.upload(E.self, h->s_bulk, h->x_soa, xs.data(), sizeof(double) * 3 * Np));
+  DCHK(E.upload(E.self, h->s_bulk, h->x_soa, xs.data(), sizeof(double) * 4 * Np));
   DCHK(E.upload(E.self, h->s_bulk, h->y, yp.data(), sizeof(double) * Np));
   DCHK(E.zero(E.self, h->s_bulk, h->alpha, sizeof(double) * Np));
   DCHK(E.zero(E.self, h->s_bulk, h->small, sizeof(double) * 16));
@@ -800,14 +804,14 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   // ---- fill: HybKerns::computeK + "(sW sW') % K + I" of ldB2_exact, owned columns only, no communication
   {
     const double n = (double)N;
-    double mu[3];
-    for (int k = 0; k < 3; k++) {   // pooled mean of X u X exactly as Kernel.cpp:1391-1392 computes it
+    double mu[4];
+    for (int k = 0; k < 4; k++) {   // pooled mean of X u X exactly as Kernel.cpp:1391-1392 computes it
       const double mX1 = n / (n + n) * h->xsum[k] / n;
       mu[k] = n / (n + n) * h->xsum[k] / n + mX1;
     }
     DCHK(E.transform(h->s_bulk, h->x_soa, Np, N, h->cap, h->expans, mu, h->u));
     for (int b : h->owned)
-      DCHK(E.fill_b(h->s_bulk, h->u, h->cap, N, Np, h->start(b), h->width(b), h->expans, h->bias, h->sn2, h->mode,
+      DCHK(E.fill_b(h->s_bulk, h->u, h->cap, N, Np, h->start(b), h->width(b), h->expans, h->bias, h->sn2, h->kmode(),
                     h->blk(b), h->ld));
   }
   DCHK(E.vec_scale(h->s_bulk, Np, h->y, 1.0 / h->sn2, h->rhs));            // rhs = y / sn2
@@ -839,7 +843,7 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   DCHK(E.zero(E.self, h->s_bulk, h->f, sizeof(double) * Np));
   const size_t tk0 = h->time_event(h->s_bulk);
   if (i1 > i0)
-    DCHK(E.kmatvec(h->s_bulk, h->u, h->cap, N, i0, i1, h->alpha, h->expans, h->bias, h->mode, h->scratch, h->f));
+    DCHK(E.kmatvec(h->s_bulk, h->u, h->cap, N, i0, i1, h->alpha, h->expans, h->bias, h->kmode(), h->scratch, h->f));
   const size_t tk1 = h->time_event(h->s_bulk);
   DCHK(hop_in(h));
   DCHK(T.allreduce_sum(T.self, h->s_comm, h->f, (size_t)Np));
@@ -933,7 +937,7 @@ int gpak_dist_grad(gpak_dist *h, double *g) {
   DCHK(hop_out(h));
   DCHK(E.grad_binv_rows(h->s_bulk, Np, P, h->rank, h->slabs.data(), h->binv));
   DCHK(E.grad_pairs_rows(h->s_bulk, h->u, h->cap, h->x_soa, Np, h->N, Np, h->y, h->f, h->alpha, h->binv, P, h->rank,
-                         h->expans, h->bias, h->sn2, h->mode, h->gpart, h->gred));
+                         h->expans, h->bias, h->sn2, h->kmode(), h->gpart, h->gred));
   DCHK(hop_in(h));
   DCHK(T.allreduce_sum(T.self, h->s_comm, h->gred, 16));
   DCHK(hop_out(h));
@@ -941,7 +945,7 @@ int gpak_dist_grad(gpak_dist *h, double *g) {
   double red[17];
   DCHK(E.download(E.self, h->s_bulk, red, h->gred, sizeof(red)));
   E.event_elapsed_ms(E.self, h->ev_time[t0], h->ev_time[t1], &h->grad_ms);
-  return gpak_dev_grad_finish(h->expans, h->bias, h->sn2, h->N, red, g);
+  return gpak_dev_grad_finish_d(h->expans, h->bias, h->sn2, h->N, h->d, red, g);
 }
 
 int gpak_dist_get_stats(gpak_dist *h, gpak_dist_stats *out) {

@@ -492,7 +492,10 @@ extern "C" int gpak_dev_grad_pairs_rows(void *stream, const double *u, int cap, 
   gpak_build_siginv(expans, kp.term[0].A);
   kp.term[0].var2 = expans[6] * expans[6];
   kp.term[0].profile = GPAK_PROFILE_EXPSQRT;
-  kp.d = 3; kp.bias = bias; kp.mode = dist_mode;
+  const bool d4 = (dist_mode & GPAK_DIST_D4) != 0;
+  dist_mode &= 0xF;
+  kp.term[0].a33 = expans[7];
+  kp.d = d4 ? 4 : 3; kp.bias = bias; kp.mode = dist_mode;
   GradConsts gc;
   memset(&gc, 0, sizeof(gc));
   build_grad_consts(expans, gc);
@@ -503,7 +506,8 @@ extern "C" int gpak_dev_grad_pairs_rows(void *stream, const double *u, int cap, 
     dim3 grid(Ta, Np / GT_COLS);
     const int nblocks = (int)(grid.x * grid.y);
     hipLaunchKernelGGL(gpak_grad_pairs_f64, grid, dim3(256), 0, st, u, cap, x_soa, x_soa + xs, x_soa + 2 * (size_t)xs,
-                       (const double *)nullptr, alpha, binv, (long)Ta * PB, n, kp, gc, part, P, a, Tmax);
+                       d4 ? x_soa + 3 * (size_t)xs : (const double *)nullptr, alpha, binv, (long)Ta * PB, n, kp, gc, part, P, a,
+                       Tmax);
     hipLaunchKernelGGL(gpak_grad_reduce_f64, dim3(NSUM), dim3(256), 0, st, part, nblocks, out);
   }
   hipLaunchKernelGGL(gpak_lpdhyp_f64, dim3(1), dim3(1024), 0, st, n, y, f, sn2, out + NSUM);
@@ -522,13 +526,17 @@ extern "C" int gpak_dev_grad_consts(const double *expans, double *M36, double *m
 }
 
 // host side of the distributed gradient: g[10] from the all-reduced sums
-extern "C" int gpak_dev_grad_finish(const double *expans, double bias, double sn2, int n, const double *red, double *g) {
+extern "C" int gpak_dev_grad_finish_d(const double *expans, double bias, double sn2, int n, int d, const double *red,
+                                      double *g) {
   KernParams kp;
   memset(&kp, 0, sizeof(kp));
   kp.nterms = 1;
   kp.term[0].var2 = expans[6] * expans[6];
   kp.bias = bias;
   const int kinds[GPAK_MAX_TERMS] = {GPAK_KERN_EXPANS, 0, 0};
-  gpak_grad_assemble(kp, kinds, expans, 3, n, sn2, red, g);
+  gpak_grad_assemble(kp, kinds, expans, d == 4 ? 4 : 3, n, sn2, red, g);
   return GPAK_OK;
+}
+extern "C" int gpak_dev_grad_finish(const double *expans, double bias, double sn2, int n, const double *red, double *g) {
+  return gpak_dev_grad_finish_d(expans, bias, sn2, n, 3, red, g);
 }

@@ -378,7 +378,7 @@ const char *gpak_multi_transport(gpak_multi *g) { return g->transport_name.c_str
 int gpak_multi_failed_column(gpak_multi *g) { return g->failed_col; }
 
 int gpak_multi_set_train(gpak_multi *g, const double *X, const double *y, int N, int d) {
-  if (d != 3) { g->err = "a multi-GPU context handles 3-D inputs"; return GPAK_ENOTIMPL; }
+  if (d != 3 && d != 4) { g->err = "inputs must have 3 or 4 columns"; return GPAK_ENOTIMPL; }
   g->X.assign(X, X + (size_t)N * d); g->y.assign(y, y + N);
   g->N = N; g->d = d;
   std::fill(g->replica_train_ok.begin(), g->replica_train_ok.end(), 0);

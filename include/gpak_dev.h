@@ -20,6 +20,12 @@
 extern "C" {
 #endif
 
+/* Inputs with a 4th ("rock type") column (Kernel.cpp:1411-1424): the raw points x are ALWAYS four SoA
+ * columns of stride xs (the 4th all zero for 3-D inputs: its transformed coordinate is then 0 and every result is
+ * bit-identical to the 3-column arithmetic), mu has four entries, and the calls that evaluate the kernel take
+ * GPAK_DIST_D4 OR-ed into dist_mode to select the 4-coordinate distance. */
+#define GPAK_DIST_D4 0x10
+
 /* u = (x - mu) * sigInv for the N points, SoA: u is 5*cap doubles {u0[cap],u1[cap],u2[cap],|u|^2[cap],u3[cap]}
  * (u3 = transformed 4th input column of the context-level API; zero here, the distributed path is 3-D).
  * x is SoA with stride xs.  mu[3] is the pooled mean (Kernel.cpp:1391-1392), expans[8] as gpak_set_params. */
@@ -107,6 +113,8 @@ int gpak_dev_grad_pairs_rows(void *stream, const double *u, int cap, const doubl
                              const double *y, const double *f, const double *alpha, const double *binv, int P, int a,
                              const double *expans, double bias, double sn2, int dist_mode, double *part, double *out);
 int gpak_dev_grad_finish(const double *expans, double bias, double sn2, int n, const double *red, double *g);
+/* the same for d input columns (3 or 4): with a rock-type column g[7] is the InversewidthR slot (Kernel.cpp:1246-1255) */
+int gpak_dev_grad_finish_d(const double *expans, double bias, double sn2, int n, int d, const double *red, double *g);
 /* host only: the constants of the pair pass, M36 = M_p (6 x {00,01,02,11,12,22}), m2_18 = 2 * column sums of M_p */
 int gpak_dev_grad_consts(const double *expans, double *M36, double *m2_18);
 

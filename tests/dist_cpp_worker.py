@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--grad", type=int, default=0)
     ap.add_argument("--corrupt", type=int, default=0)
+    ap.add_argument("--d", type=int, default=3, help="input columns (4: with a rock-type column)")
     ap.add_argument("--grid", default="", help="PrxPc: the row-block x column-block layout (gpak_grid_*)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -49,7 +50,7 @@ def main():
         from np_dist_engine import GlooTransport, NumpyDistEngine
         eng, tr = NumpyDistEngine(), GlooTransport(corrupt_first=a.corrupt)
         gp = gd.DistRank(a.rank, a.world, engine=eng, transport=tr)
-    X, y = synth.drillholes(max(a.n, 4))
+    X, y = synth.drillholes4(max(a.n, 4)) if a.d == 4 else synth.drillholes(max(a.n, 4))
     X, y = X[:a.n].copy(order="F"), y[:a.n].copy()
     gp.set_train(X, y, nb=a.nb)
     sn2 = synth.DEFAULT_SN2 if a.sn2 is None else a.sn2

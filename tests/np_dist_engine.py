@@ -62,7 +62,7 @@ class NumpyDistEngine:
             ms[0] = 0.0
 
         def transform(st, x, xs, n, cap, expans, mu, u):
-            eng.transform(_t(x, 3 * xs), xs, n, cap, [expans[i] for i in range(8)], [mu[i] for i in range(3)], _t(u, 5 * cap))
+            eng.transform(_t(x, 4 * xs), xs, n, cap, [expans[i] for i in range(8)], [mu[i] for i in range(4)], _t(u, 5 * cap))
 
         def fill_b(st, u, cap, n, Np, J, W, expans, bias, sn2, mode, blk, ld):
             eng.fill_b(_t(u, 5 * cap), cap, n, Np, J, W, [expans[i] for i in range(8)], bias, sn2, mode, _t(blk, W * ld), ld)
@@ -197,7 +197,10 @@ class NumpyDistEngine:
                 Mp[p] = [[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]]
             m2 = m2.reshape(6, 3)
             un = _arr(u, 5 * cap).reshape(5, cap)
-            X = _arr(x_soa, 3 * xs).reshape(3, xs)[:, :n].T
+            d4 = bool(mode & 0x10)
+            mode &= 0xF
+            X4 = _arr(x_soa, 4 * xs).reshape(4, xs)[:, :n].T
+            X = X4[:, :3]
             al, yn, fn = _arr(alpha, Np)[:n], _arr(y, Np)[:n], _arr(f, Np)[:n]
             rows, Tmax = my_rows(Np, P, a), my_tiles(Np, P, 0)
             acc = np.zeros(17)
@@ -209,7 +212,8 @@ class NumpyDistEngine:
                 cperm = ((cols // TILE % P) * Tmax + cols // TILE // P) * TILE + cols % TILE
                 loc = np.concatenate([np.arange(t * TILE, (t + 1) * TILE) for t in range(my_tiles(Np, P, a))])[:len(rows)]
                 Q = Bperm[loc][:, cperm]                              # (my rows) x n
-                Pu, Qu = un[:3, rows].T, un[:3, :n].T
+                sel = [0, 1, 2, 4] if d4 else [0, 1, 2]
+                Pu, Qu = un[sel][:, rows].T, un[sel][:, :n].T
                 if mode == 1:
                     D2 = ((Pu[:, None, :] - Qu[None, :, :]) ** 2).sum(-1)
                 else:
@@ -227,6 +231,9 @@ class NumpyDistEngine:
                 acc[7] = (wgt * Q * (bias + var2 * ek)).sum()
                 acc[8] = (QW * diag).sum()
                 acc[6] = (wgt * QW * ek).sum()
+                if d4:       # Kernel.cpp:1246-1255: weight KD2 (not R), Di2_R = 2 (x4_i - x4_j)^2; g7 = -4 acc[15] / N
+                    dx = X4[rows, 3][:, None] - X4[:, 3][None, :]
+                    acc[15] = (wgt * ek * dx * dx).sum()
                 for p in range(6):
                     pa_i = (X[rows] ** 2) @ m2[p]
                     pa_j = (X ** 2) @ m2[p]

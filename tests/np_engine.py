@@ -30,16 +30,23 @@ class NumpyEngine:
         return orc.siginv(par)
 
     def transform(self, x_soa, xs, n, cap, expans, mu, u):
-        X = x_soa.numpy().reshape(3, xs)[:, :n].T
-        U = (X - np.asarray(mu)[None, :]) @ self._A(expans)
+        # FOUR raw columns (include/gpak_dev.h): the 4th is zero for 3-D inputs, its image u3 = InversewidthR * (x3 - mu3)
+        X4 = x_soa.numpy().reshape(4, xs)[:, :n].T
+        mu = list(mu) + [0.0] * (4 - len(mu))
+        U = (X4[:, :3] - np.asarray(mu[:3])[None, :]) @ self._A(expans)
+        u3 = expans[7] * (X4[:, 3] - mu[3])
         un = u.numpy().reshape(5, cap)
         un[:] = 0
         un[:3, :n] = U.T
-        un[3, :n] = (U * U).sum(1)
+        un[4, :n] = u3
+        un[3, :n] = (U * U).sum(1) + u3 * u3
 
     @staticmethod
     def _kfun(un, rows, cols, expans, bias, mode):
-        P, Q = un[:3, rows].T, un[:3, cols].T
+        d4 = bool(mode & 0x10)            # GPAK_DIST_D4: the transformed 4th column takes part in the distance
+        mode &= 0xF
+        sel = [0, 1, 2, 4] if d4 else [0, 1, 2]
+        P, Q = un[sel][:, rows].T, un[sel][:, cols].T
         if mode == 1:
             D2 = ((P[:, None, :] - Q[None, :, :]) ** 2).sum(-1)
         else:

@@ -141,7 +141,7 @@ class HipEngine:
 
     # -- tile operations (include/gpak_dev.h) ---------------------------------------------------
     def transform(self, x_soa, xs, n, cap, expans, mu, u):
-        m = (C.c_double * 3)(*[float(v) for v in mu])
+        m = (C.c_double * 4)(*([float(v) for v in mu] + [0.0] * (4 - len(mu))))
         self._chk(self.lib.gpak_dev_transform(self._st(), self._p(x_soa), xs, n, cap, self._e(expans), m,
                                               self._p(u)), "gpak_dev_transform")
 
@@ -233,8 +233,8 @@ class DistGP:
         self.nJ = (self.Np + self.nb - 1) // self.nb
         self.cap = self.Np
         self.owned = [b for b in range(self.nJ) if b % self.P == self.rank]
-        xs = np.zeros((3, self.Np))
-        xs[:, :self.N] = X.T
+        xs = np.zeros((4, self.Np))          # four raw columns (include/gpak_dev.h), the 4th zero for 3-D inputs
+        xs[:3, :self.N] = X.T
         self.x_soa = engine.from_numpy(xs.ravel())
         yp = np.zeros(self.Np)
         yp[:self.N] = y

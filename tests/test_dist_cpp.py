@@ -32,7 +32,8 @@ def free_port():
     return p
 
 
-def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0, corrupt=0, env=None, grid=None):
+def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0, corrupt=0, env=None, grid=None,
+              ncols=3):
     port = free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
@@ -45,6 +46,8 @@ def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=9
                 cmd += ["--sn2", str(sn2)]
             if grid is not None:
                 cmd += ["--grid", f"{grid[0]}x{grid[1]}"]
+            if ncols != 3:
+                cmd += ["--d", str(ncols)]
             penv = dict(os.environ, OMP_NUM_THREADS="2", **(env or {}))
             procs.append(subprocess.Popen(cmd, env=penv, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
@@ -187,6 +190,55 @@ def test_cpp_schedule_hip_engine_plain_stream_fallback(orc):
         assert r["stats"]["flags"] == 3
         assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
         assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+
+
+def _oracle_d4(orc, n, mode=1):
+    X, y = synth.drillholes4(n)
+    e = np.array(synth.DEFAULT_EXPANS)
+    K = orc.gram(X, X, e, synth.DEFAULT_BIAS, mode)
+    info, alpha, L = orc.nlz_lean(K, y, synth.DEFAULT_SN2)
+    g = orc.grad_ref(X, y, K, L, alpha, e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, mode)
+    return info, alpha, g
+
+
+@pytest.mark.parametrize("world,n,nb,grid", [(2, 500, 128, None), (3, 900, 256, None), (4, 700, 128, (2, 2))])
+def test_four_column_inputs_on_the_distributed_paths(orc, world, n, nb, grid):
+    """SURVEY Q7 on more than one rank: x, y, z + rock type (InversewidthR in the distance, g[7] != 0) through the 1-D
+    schedule (nlZ, alpha, gradient) and the 2-D grid (nlZ, alpha), NumPy engine over gloo, against the oracle."""
+    res = run_world(world, n, nb, ncols=4, grid=grid, grad=0 if grid else 1)
+    info, alpha, g = _oracle_d4(orc, n)
+    for r in res:
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz)
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+        if grid is None:
+            assert g[7] != 0.0 and np.abs(np.array(r["grad"]) - g).max() <= 1e-8 * np.abs(g).max()
+
+
+@pytest.mark.gpu
+def test_four_column_inputs_on_a_multi_gpu_context(orc):
+    """The same through gpak_create_multi on the HIP engine (three ranks on this box's GPU): nlZ, alpha, gradient with
+    g[7], and the sharded prediction with a rock-type column in the test points."""
+    from gp_ss_ak_amd import gpak
+    n = 1500
+    X, y = synth.drillholes4(n)
+    Xt = synth.test_points4(300)
+    e = np.array(synth.DEFAULT_EXPANS)
+    info, alpha, go = _oracle_d4(orc, n)
+    K = orc.gram(X, X, e, synth.DEFAULT_BIAS, orc.DIST_DIRECT)
+    _, _, L = orc.nlz_lean(K, y, synth.DEFAULT_SN2)
+    g = gpak.Gpak(devices=[0, 0, 0])
+    try:
+        g.set_train(X, y)
+        g.set_params(e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
+        assert abs(g.logLikelihood() - info.nlz) <= 1e-9 * abs(info.nlz)
+        assert np.abs(g.solve_alpha() - alpha).max() <= 1e-8 * np.abs(alpha).max()
+        gg = g.GradLL()
+        assert gg[7] != 0.0 and np.abs(gg - go).max() <= 1e-8 * np.abs(go).max()
+        mean, var = g.posteriorMeanVar(Xt)
+        mo, vo = orc.predict(X, Xt, e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, alpha, L, orc.DIST_DIRECT, 0)
+        assert np.abs(mean - mo).max() <= 1e-8 * np.abs(mo).max() and np.abs(var - vo).max() <= 1e-8 * np.abs(vo).max()
+    finally:
+        g.close()
 
 
 # ---- the row-block x column-block layout (gpak_grid_*, csrc/grid.inc) ----------------------------------------------
