@@ -124,6 +124,17 @@ def _timed_steps(g, mode, steps, warmup):
     return time.perf_counter() - t0, nlz, phases, launches
 
 
+def _sources_sha16():
+    """Fingerprint of the kernel / schedule sources the dominant kernel's behaviour depends on: the PMC summary
+    records it when it is made (tools/pmc_summary.py), bench.py recomputes it -- a profile of other code is flagged."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "potrf.hip", "api.hip", "gpak_internal.h"):
+        with open(os.path.join(ROOT, "gp_ss_ak_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _pmc(tag, N):
     """HBM-side traffic and in-situ clock of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
     command (profiles/<tag>_pmc_summary_N<N>.json, written by tools/profile_round.sh <tag>): per launch,
@@ -132,7 +143,9 @@ def _pmc(tag, N):
     if not os.path.exists(path):
         return None
     z = json.load(open(path))
-    out = {"source": os.path.relpath(path, ROOT)}
+    out = {"source": os.path.relpath(path, ROOT), "profile_sources_sha16": z.get("sources_sha16"),
+           "current_sources_sha16": _sources_sha16()}
+    out["stale"] = out["profile_sources_sha16"] != out["current_sources_sha16"]
 
     def pick(section):   # the bulk trailing update: gpak_gemm_nt_f64_rs<4, 2, true[, false]>
         for name, v in z.get(section, {}).items():
@@ -266,9 +279,16 @@ def run_single(args):
     tag = args.profile_tag
     out["profile_tag"] = tag
     pm = _pmc(tag, N)
-    if pm is not None:
+    if pm is not None and pm["stale"]:
+        # the committed profile was taken on other kernel / schedule sources than the ones running now: its counters are
+        # not this code's -- reported as absent, with the reason, rather than quoted
+        out["roofline"]["traffic"] = None
+        out["roofline"]["traffic_note"] = (f"{pm['source']} was recorded on sources {pm['profile_sources_sha16']}, this run "
+                                           f"has {pm['current_sources_sha16']}: re-run tools/profile_round.sh {tag}")
+    elif pm is not None:
         out["roofline"]["traffic"] = pm.get("traffic")
-        out["roofline"]["traffic_source"] = pm["source"] + " (2*FETCH_SIZE + WRITE_SIZE per launch)"
+        out["roofline"]["traffic_source"] = (pm["source"] + " (2*FETCH_SIZE + WRITE_SIZE per launch; separate --pmc passes of "
+                                             "this command on the same sources, sha " + str(pm["current_sources_sha16"]) + ")")
         if "grbm_gui_active_per_launch" in pm and out["roofline"]["avg_launch_ms"]:
             # GRBM_GUI_ACTIVE counts per XCD; the collected value is the sum over the 8 XCDs
             ghz = pm["grbm_gui_active_per_launch"] / 8.0 / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
@@ -314,6 +334,37 @@ def run_single(args):
         out["config2"] = {"N": args.config2, "steps_per_s": 20 / w2, "ms_per_step": w2 / 20 * 1e3,
                           "nlz_step0_params": g.logLikelihood(),
                           "factor_ms": ph2["factor_ms"] / 20, "gram_ms": ph2["gram_ms"] / 20}
+    if args.config5 and N == 32768:
+        # BASELINE.json configs[4]: N=32768, M=1e6 block-model points, fp32 prediction (GPAK_F32 context: fp64 training
+        # step; fp32 cross-kernel / forward substitution -- fp32 MFMA chunks of K=128 summed in fp64 -- / variance sums),
+        # with the fp64 context on the first 65536 points as the accuracy reference of the same run
+        M5 = args.config5
+        X5, y5 = synth.drillholes(N)
+        Xt5 = synth.test_points(M5)
+        e0, b0, s0 = params_for_step(0)
+        g32 = gpak.Gpak(int(os.environ.get("LOCAL_RANK", "0")), gpak.F32)
+        g32.set_train(X5, y5)
+        g32.set_params(e0, b0, s0, mode)
+        g32.logLikelihood()
+        g32.posteriorMeanVar(Xt5[:512])                     # buffers + the fp32 image of the factor
+        t0 = time.perf_counter()
+        m32, v32 = g32.posteriorMeanVar(Xt5)
+        w32 = time.perf_counter() - t0
+        g32.close()
+        g.set_train(X5, y5)
+        g.set_params(e0, b0, s0, mode)
+        Mref = min(M5, 65536)
+        t0 = time.perf_counter()
+        m64, v64 = g.posteriorMeanVar(Xt5[:Mref])
+        w64 = time.perf_counter() - t0
+        out["config5"] = {"N": N, "M": M5, "precision": "fp64 fill / factorisation / alpha / mean; fp32 MFMA for the "
+                          "M-proportional variance work, accumulated in fp64 across K=128 chunks",
+                          "wall_s": w32, "points_per_s": M5 / w32,
+                          "variance_tflops": float(N) * N * M5 / w32 / 1e12,
+                          "frac_of_fp32_mfma_peak": float(N) * N * M5 / w32 / 1e12 / 157.3,
+                          "fp64_reference": {"M": Mref, "wall_s": w64, "variance_tflops": float(N) * N * Mref / w64 / 1e12,
+                                             "variance_max_rel_diff": float(np.abs(v32[:Mref] - v64).max() / v64.max()),
+                                             "mean_max_rel_diff": float(np.abs(m32[:Mref] - m64).max() / np.abs(m64).max())}}
     g.close()
     if args.config3 and N == 32768:
         out["config3"] = config3(args.config3, N)
@@ -477,6 +528,8 @@ def main():
                                                                "reference sequence at full size; 0 = skip)")
     ap.add_argument("--config3", type=int, default=3, help="L-BFGS iterations of the configs[2] sub-run through the CLI "
                                                             "(N=32768 only; 0 = skip)")
+    ap.add_argument("--config5", type=int, default=1000000, help="test points of the configs[4] sub-run (N=32768 fp32 "
+                                                                  "prediction; 0 = skip)")
     ap.add_argument("--grid", default="auto", help="N > 1: also time the row-block x column-block layouts: PrxPc, 'auto' "
                                                     "(every Pr in 2, 4, 8 dividing N) or 'none'")
     ap.add_argument("--inproc", action="store_true", help="N > 1: one process, one host thread per GPU (gpak_create_multi)")

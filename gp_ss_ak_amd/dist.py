@@ -492,38 +492,7 @@ def bench(args):
     if int(flag.item()) == 0:
         raise RuntimeError(f"distributed start-up failed: {why}")
     res = _one_size(args, args.n, dist, rank, world, local, make_rank, args.steps, args.warmup, bench_mod)
-    extra = None
-    if args.n != 65536 and not args.no_n65536:
-        # north_star's scaling curve is quoted at N=65536 (BASELINE.json configs[3]): a short run of that size rides
-        # along as a sub-object; it needs 32 GiB / P + 17 GB per GPU
-        extra = _one_size(args, 65536, dist, rank, world, local, make_rank, max(1, min(args.steps, 3)), 1, bench_mod)
-    # the row-block x column-block layouts of the same world size (north_star's 2-D sharding, csrc/grid.inc) ride along:
-    # a short run per grid, so that one line holds both layouts' step time and bytes received per rank (DESIGN.md 5)
-    grids = []
-    want = getattr(args, "grid", "auto")
-    if want != "none":
-        shapes = ([tuple(int(v) for v in want.split("x"))] if want not in ("auto", "") else
-                  [(pr, world // pr) for pr in (2, 4, 8) if world % pr == 0 and pr <= world])
-        for (gr, gc) in shapes:
-            if gr * gc != world or gr < 2:
-                continue
-
-            def make_grid(gr=gr, gc=gc):
-                if staged:
-                    return GridRank(rank, world, gr, gc, device=local, transport=StagedTransport())
-                ids = [DistRank.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                return GridRank(rank, world, gr, gc, device=local, rccl_id=ids[0])
-            ok, why = 1, ""
-            try:
-                g_res = _one_size(args, args.n, dist, rank, world, local, make_grid, max(1, min(args.steps, 3)), 1, bench_mod)
-            except Exception as e:   # noqa: BLE001 -- a layout that cannot start is reported, not fatal
-                ok, why, g_res = 0, f"{type(e).__name__}: {e}", None
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            grids.append(((gr, gc), g_res if int(flag.item()) else None, why))
-    out = None
-    if rank == 0:
+    def build(res, extra, grids):
         def line(r, steps):
             Np = r["stats"]["n_padded"]
             flops = Np ** 3 / 3.0
@@ -577,5 +546,62 @@ def bench(args):
                     "phases_ms_per_rank": gl["phases_ms_per_rank"]})
             out["grid_layouts_note"] = ("1-D block-column-cyclic (the headline value above) receives (P-1)/P * N^2/2 * 8 B per "
                                         "rank and step: " + str(8.0 * res["stats"]["n_padded"] ** 2 / 2 * (world - 1) / world))
+        return out
+
+    # The headline measurement is complete here.  What follows is optional (the N=65536 point, the grid layouts -- code
+    # paths no multi-GPU node has run yet): a watchdog guarantees that a sub-run that hangs cannot take the headline
+    # line with it -- at the deadline rank 0 prints what it has and every rank leaves.
+    import json
+    import sys
+    import threading
+    state = {"extra": None, "grids": [], "phase": "start"}
+    deadline = float(os.environ.get("GPAK_BENCH_EXTRAS_TIMEOUT_S", "300"))
+
+    def on_timeout():
+        if rank == 0:
+            o = build(res, state["extra"], state["grids"])
+            o["extras_note"] = (f"optional sub-runs stopped by the {deadline:.0f} s watchdog (in: {state['phase']}); the "
+                                f"headline numbers are complete")
+            print(json.dumps(o), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+    timer = threading.Timer(deadline, on_timeout)
+    timer.daemon = True
+    timer.start()
+    extra = None
+    if args.n != 65536 and not args.no_n65536:
+        # north_star's scaling curve is quoted at N=65536 (BASELINE.json configs[3]): a short run of that size rides
+        # along as a sub-object; it needs 32 GiB / P + 17 GB per GPU
+        state["phase"] = "N=65536"
+        extra = _one_size(args, 65536, dist, rank, world, local, make_rank, max(1, min(args.steps, 3)), 1, bench_mod)
+    # the row-block x column-block layouts of the same world size (north_star's 2-D sharding, csrc/grid.inc) ride along:
+    # a short run per grid, so that one line holds both layouts' step time and bytes received per rank (DESIGN.md 5)
+    state["extra"] = extra
+    grids = state["grids"]
+    want = getattr(args, "grid", "auto")
+    if want != "none":
+        shapes = ([tuple(int(v) for v in want.split("x"))] if want not in ("auto", "") else
+                  [(pr, world // pr) for pr in (2, 4, 8) if world % pr == 0 and pr <= world])
+        for (gr, gc) in shapes:
+            if gr * gc != world or gr < 2:
+                continue
+
+            def make_grid(gr=gr, gc=gc):
+                if staged:
+                    return GridRank(rank, world, gr, gc, device=local, transport=StagedTransport())
+                ids = [DistRank.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                return GridRank(rank, world, gr, gc, device=local, rccl_id=ids[0])
+            ok, why = 1, ""
+            state["phase"] = f"grid {gr}x{gc}"
+            try:
+                g_res = _one_size(args, args.n, dist, rank, world, local, make_grid, max(1, min(args.steps, 3)), 1, bench_mod)
+            except Exception as e:   # noqa: BLE001 -- a layout that cannot start is reported, not fatal
+                ok, why, g_res = 0, f"{type(e).__name__}: {e}", None
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            grids.append(((gr, gc), g_res if int(flag.item()) else None, why))
+    timer.cancel()
+    out = build(res, extra, grids) if rank == 0 else None
     dist.destroy_process_group()
     return out

@@ -21,5 +21,13 @@ if __name__ == "__main__":
     for spec in sys.argv[2:]:
         name, d = spec.split("=", 1)
         res[name] = summarise(d)
+    # fingerprint of the sources these counters belong to (bench.py compares it with the sources it runs on)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import bench
+        res["sources_sha16"] = bench._sources_sha16()
+    except Exception as e:   # noqa: BLE001
+        res["sources_sha16"] = None
+        res["sources_sha16_error"] = str(e)
     json.dump(res, open(sys.argv[1], "w"), indent=1)
-    print("wrote", sys.argv[1], {k: len(v) for k, v in res.items()})
+    print("wrote", sys.argv[1], {k: len(v) for k, v in res.items() if isinstance(v, dict)})

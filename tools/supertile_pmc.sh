@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/supertile
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu --no-n65536 --config3 0 --config2 0"
+ARGS="--no-cpu --no-n65536 --config3 0 --config2 0 --config5 0"
 for LR in 3 2 4; do
   export GPAK_SUPER_LR=$LR
   python3 $ROOT/bench.py --steps 10 --warmup 3 $ARGS > $OUT/bench_lr$LR.json 2> $OUT/bench_lr$LR.err
