@@ -346,7 +346,7 @@ def run_single(args):
         g32.set_train(X5, y5)
         g32.set_params(e0, b0, s0, mode)
         g32.logLikelihood()
-        g32.posteriorMeanVar(Xt5[:512])                     # buffers + the fp32 image of the factor
+        g32.posteriorMeanVar(Xt5[:min(M5, 65536)])          # one full batch: buffers + the fp32 image of the factor
         t0 = time.perf_counter()
         m32, v32 = g32.posteriorMeanVar(Xt5)
         w32 = time.perf_counter() - t0
