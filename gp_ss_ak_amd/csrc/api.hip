@@ -48,6 +48,7 @@ static GpakTuning read_tuning_env() {
   geti("GPAK_TAIL_ROWS", t.tail_rows);
   getb("GPAK_SUB_NEXT", t.sub_next);
   getb("GPAK_INV512", t.inv512);
+  geti("GPAK_BWD_BLOCK", t.bwd_block);
   getb("GPAK_LOOKAHEAD", t.lookahead);
   getb("GPAK_FWD_IN_FACTOR", t.fwd_in_factor);
   geti("GPAK_POTRF_CO", t.potrf_co);
@@ -334,14 +335,19 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
     ctx->xsum[k] = s;
   }
   const int T = Np / GPAK_TILE;
+  // width of the back substitution's explicit diagonal-block inverses (fixed per training set: it sizes dInv512)
+  int bw = ctx->tune.bwd_block;
+  if (bw != 512 && bw != 1024 && bw != 2048) bw = 512;
+  ctx->bwd_bw = bw;
   if (hipMalloc(&ctx->dX, sizeof(double) * 4 * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dy, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dM, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
       hipMalloc(&ctx->dInv, sizeof(double) * (size_t)T * 2 * GPAK_TILE * GPAK_TILE) != hipSuccess ||
-      hipMalloc(&ctx->dInv512, sizeof(double) * (size_t)((Np + 511) / 512) * 512 * 512) != hipSuccess ||
+      hipMalloc(&ctx->dInv512, sizeof(double) * (size_t)((Np + bw - 1) / bw) * bw * bw) != hipSuccess ||
       hipMalloc(&ctx->dAlpha, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dF, sizeof(double) * (size_t)Np) != hipSuccess ||
-      hipMalloc(&ctx->dWork, sizeof(double) * 70 * (size_t)Np) != hipSuccess) {
+      // 70 Np doubles of vectors + the back substitution's scratch for the widest block ((8 + bw / 32) * bw, solve.hip)
+      hipMalloc(&ctx->dWork, sizeof(double) * (70 * (size_t)Np + (size_t)(8 + bw / 32) * bw)) != hipSuccess) {
     ctx->err = "device allocation failed for the training set";
     release_train(ctx);
     return GPAK_ENOMEM;
@@ -507,7 +513,7 @@ static int ensure_alpha(gpak_ctx *ctx) {
   }
   ctx->z_ok = false;  // the back substitution consumes w1
   gpak_launch_trsv_bwd2(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha, ctx->dWork + 2 * (size_t)ctx->Np,
-                        ctx->inv512_ok ? ctx->dInv512 : nullptr);
+                        ctx->inv512_ok ? ctx->dInv512 : nullptr, ctx->bwd_bw);
   GPAK_HIP(hipEventRecord(ctx->ev[4], st));
   GPAK_HIP(hipEventSynchronize(ctx->ev[4]));
   float ms = 0;

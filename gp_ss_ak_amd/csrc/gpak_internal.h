@@ -60,7 +60,10 @@ struct GpakTuning {
   bool first_narrow = true;    // GPAK_FIRST_NARROW  the very first panel is nb_outer wide
   int tail_rows = 12288;       // GPAK_TAIL_ROWS     rows left from which the bulk updates use the CU-masked queue
   bool sub_next = false;       // GPAK_SUB_NEXT      tail: next block column updated sub-panel by sub-panel
-  bool inv512 = true;          // GPAK_INV512        explicit 512-block inverses for the back substitution
+  bool inv512 = true;          // GPAK_INV512        explicit diagonal-block inverses for the back substitution
+  int bwd_block = 512;         // GPAK_BWD_BLOCK     ... of this width: 512, 1024 or 2048 columns per back-substitution step
+                               //                    (measured round 3: solve 1.72 / 1.42 / 1.33 ms at N = 32768, but the wider inverses cost
+                               //                    the factorisation as much or more: profiles/r03_bwd_block.txt)
   bool lookahead = true;       // GPAK_LOOKAHEAD     0: everything on one stream
   bool fwd_in_factor = true;   // GPAK_FWD_IN_FACTOR forward substitution of y/sn2 rides along with the factorisation
   int potrf_co = 1;            // GPAK_POTRF_CO      0 always the 8-wave block kernel, 2 always the 4-wave one, 1 as asked
@@ -120,7 +123,8 @@ struct gpak_ctx {
   DevPoints U;               // transformed training points
   double *dM = nullptr;      // Np x ld matrix buffer: B then L (lower)
   double *dInv = nullptr;    // (Np/128) inverted 128x128 diagonal blocks of L
-  double *dInv512 = nullptr; // (Np/512) explicit (L_bb^-1)^T of the 512x512 diagonal blocks (back substitution)
+  double *dInv512 = nullptr; // explicit (L_bb^-1)^T of the bw x bw diagonal blocks (bw = bwd_bw; back substitution)
+  int bwd_bw = 512;          // block width dInv512 was sized and is being built for
   bool inv512_ok = false;
   double *dAlpha = nullptr;  // Np
   double *dWork = nullptr;   // 4*Np scratch vectors
@@ -327,11 +331,12 @@ void gpak_launch_trsv_fwd(hipStream_t st, int Np, const double *L, long ld, cons
                           double *out);
 // two-level variant: z is read-only, scratch holds 8 * 512 doubles
 void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const double *L, long ld, const double *inv,
-                                 const double *z, double *out, double *scratch, const double *Rinv = nullptr);
+                                 const double *z, double *out, double *scratch, const double *Rinv = nullptr, int NB = 512);
 // R = (L_bb^-1)^T of the W x W diagonal block at J (W <= 512), column-major ld 512; seven small GEMM launches
-void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R);
+void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R,
+                              int RL = 512);
 void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
-                           double *out, double *scratch, const double *Rinv512 = nullptr);
+                           double *out, double *scratch, const double *RinvB = nullptr, int bw = 512);
 void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,
                           double *out);
 void gpak_launch_trsv_fwd_block(hipStream_t st, int Np, int J, int W, const double *L, long ld,

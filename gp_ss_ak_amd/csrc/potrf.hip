@@ -659,10 +659,11 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
       // explicit inverses of the 512-column diagonal blocks completed by this panel, for the back substitution
       // (same stream: off the panel chain, hidden behind the bulk updates)
       const bool inv512 = ctx->tune.inv512;
-      while (inv512 && done512 * 512 < Np && (std::min(Np, (done512 + 1) * 512) <= J + W)) {
-        const int j5 = done512 * 512;
-        gpak_launch_diag_inverse(sf, j5, std::min(512, Np - j5), ctx->dM, ctx->ld, ctx->dInv,
-                                 ctx->dInv512 + (size_t)done512 * 512 * 512);
+      const int bw = ctx->bwd_bw;
+      while (inv512 && done512 * bw < Np && (std::min(Np, (done512 + 1) * bw) <= J + W)) {
+        const int j5 = done512 * bw;
+        gpak_launch_diag_inverse(sf, j5, std::min(bw, Np - j5), ctx->dM, ctx->ld, ctx->dInv,
+                                 ctx->dInv512 + (size_t)done512 * bw * bw, bw);
         done512++;
       }
     }

@@ -262,7 +262,7 @@ int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k) {
     GPAK_HIP(hipMemcpyAsync(w0, X_host + (size_t)c * N, sizeof(double) * N, hipMemcpyHostToDevice, st));
     gpak_launch_trsv_fwd(st, Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
     gpak_launch_trsv_bwd2(st, Np, ctx->dM, ctx->ld, ctx->dInv, w1, w2, ctx->dWork + 3 * (size_t)Np,
-                          ctx->inv512_ok ? ctx->dInv512 : nullptr);
+                          ctx->inv512_ok ? ctx->dInv512 : nullptr, ctx->bwd_bw);
     GPAK_HIP(hipMemcpyAsync(X_host + (size_t)c * N, w2, sizeof(double) * N, hipMemcpyDeviceToHost, st));
   }
   GPAK_HIP(hipStreamSynchronize(st));

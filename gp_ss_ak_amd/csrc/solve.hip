@@ -217,8 +217,9 @@ __global__ void gpak_identity_w_f64(double *R, int ld, int W) {
   const int c = i / ld, r = i - c * ld;
   R[i] = (r == c) ? 1.0 : 0.0;
 }
-void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R) {
-  const int RL = BD_MAXW;
+void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R,
+                              int RL) {
+  // RL: leading dimension of R = the block width of the caller's back substitution (512 unless told otherwise)
   hipLaunchKernelGGL(gpak_identity_w_f64, dim3((W * RL + 255) / 256), dim3(256), 0, st, R, RL, W);
   const int mt = W / SB;
   for (int j0 = 0; j0 < W; j0 += SB) {
@@ -234,7 +235,7 @@ void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, lon
 
 // part[cg][i] = sum_{c in column group cg} R[i, c] * v[c],  v = z_J - sum of the column-dot partials
 #define MV_CG 32
-__global__ __launch_bounds__(256) void gpak_bwd_diag_mv_f64(int J, int W, const double *__restrict__ R,
+__global__ __launch_bounds__(256) void gpak_bwd_diag_mv_f64(int J, int W, const double *__restrict__ R, int RL,
                                                              const double *__restrict__ z,
                                                              const double *__restrict__ spart, int nsplit,
                                                              int spart_ld, double *__restrict__ part, int part_ld) {
@@ -250,18 +251,18 @@ __global__ __launch_bounds__(256) void gpak_bwd_diag_mv_f64(int J, int W, const 
   if (i >= W) return;
   double x[MV_CG];
 #pragma unroll
-  for (int c = 0; c < MV_CG; c++) x[c] = R[i + (size_t)(c0 + c) * BD_MAXW];   // zero below the diagonal (i > c)
+  for (int c = 0; c < MV_CG; c++) x[c] = R[i + (size_t)(c0 + c) * RL];   // zero below the diagonal (i > c)
   double a = 0.0;
 #pragma unroll
   for (int c = 0; c < MV_CG; c++) a = fma(x[c], v[c], a);
   part[(size_t)blockIdx.y * part_ld + i] = a;
 }
 
-// one block column [J, J+W), W <= 512.  scratch: (8 + 16) * 512 doubles.  Rinv: the block's explicit inverse
-// (gpak_launch_diag_inverse) or nullptr (then the four-phase single-workgroup kernel is used).
+// one block column [J, J+W), W <= NB.  scratch: (8 + NB / 32) * NB doubles.  Rinv: the block's explicit inverse
+// (gpak_launch_diag_inverse with RL = NB) or nullptr (then the four-phase single-workgroup kernel is used: W <= 512).
 void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const double *L, long ld, const double *inv,
-                                 const double *z, double *out, double *scratch, const double *Rinv) {
-  const int NB = BD_MAXW, rows = Np - (J + W);
+                                 const double *z, double *out, double *scratch, const double *Rinv, int NB) {
+  const int rows = Np - (J + W);
   int R = 0, per = 0;
   if (rows > 0) {
     R = (rows + 4095) / 4096;
@@ -272,23 +273,24 @@ void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const dou
   }
   if (Rinv) {
     double *mvpart = scratch + 8 * NB;
-    hipLaunchKernelGGL(gpak_bwd_diag_mv_f64, dim3((W + 255) / 256, W / MV_CG), dim3(256), 0, st, J, W, Rinv, z, scratch, R,
-                       NB, mvpart, NB);
+    hipLaunchKernelGGL(gpak_bwd_diag_mv_f64, dim3((W + 255) / 256, W / MV_CG), dim3(256), 0, st, J, W, Rinv, NB, z, scratch,
+                       R, NB, mvpart, NB);
     gpak_launch_sum_splits(st, mvpart, NB, W / MV_CG, W, out + J);
   } else {
     hipLaunchKernelGGL(gpak_trsv_bwd_diag_f64, dim3(1), dim3(1024), 0, st, J, W, L, ld, inv, z, scratch, R, NB, out);
   }
 }
 
-// scratch: 24 * 512 doubles.  Rinv512: explicit inverses of the 512-column diagonal blocks, 512 x 512 each, or nullptr
+// scratch: (8 + NB / 32) * NB doubles.  RinvB: explicit inverses of the NB-column diagonal blocks (NB x NB each, NB =
+// bw: 512, 1024 or 2048), or nullptr: then 512-column blocks with the four-phase diagonal kernel
 void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
-                           double *out, double *scratch, const double *Rinv512) {
-  const int NB = BD_MAXW;
+                           double *out, double *scratch, const double *RinvB, int bw) {
+  const int NB = RinvB ? bw : BD_MAXW;
   const int nJ = (Np + NB - 1) / NB;
   for (int b = nJ - 1; b >= 0; b--) {
     const int J = b * NB, W = min(NB, Np - J);
-    gpak_launch_trsv_bwd_block2(st, Np, J, W, L, ld, inv, z, out, scratch,
-                                Rinv512 ? Rinv512 + (size_t)b * NB * NB : nullptr);
+    gpak_launch_trsv_bwd_block2(st, Np, J, W, L, ld, inv, z, out, scratch, RinvB ? RinvB + (size_t)b * NB * NB : nullptr,
+                                NB);
   }
 }
 
