@@ -266,6 +266,13 @@ def run_single(args):
             "fill": {"kernel": "gpak_fill1_f64 (fused Gram/B fill, lower 128x64 tiles)", "bound": "hbm",
                      "achieved": fill_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": fill_gbs / PEAK_HBM_GBS,
                      "algorithmic_bytes": tim["gram_bytes"], "ms": phases["gram_ms"] / args.steps},
+            # back substitution (the forward one rides along with the factorisation): L's lower triangle streamed once
+            "solve": {"kernel": "gpak_coldot_split_f64 + gpak_bwd_diag_mv_f64 (back substitution, 64 x 3 launches at N=32768)",
+                      "bound": "hbm", "algorithmic_bytes": 8.0 * Np * (Np + 512) / 2.0,
+                      "achieved": 8.0 * Np * (Np + 512) / 2.0 / (phases["solve_ms"] / args.steps * 1e-3) / 1e9,
+                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": 8.0 * Np * (Np + 512) / 2.0 / (phases["solve_ms"] / args.steps * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                      "ms": phases["solve_ms"] / args.steps},
             "kmatvec": {"kernel": ("gpak_kmatvec1_sym_f64 (f = K alpha, K recomputed, each value used for both entries)" if kmv_sym
                                    else "gpak_kmatvec1_part_f64 (f = K alpha, K recomputed, nothing stored)"),
                         "bound": "valu_f64",
