@@ -24,6 +24,9 @@ int gpak_multi_nlz(gpak_multi *g, double *nlz, double *quad, double *sumlp, doub
 int gpak_multi_alpha(gpak_multi *g, double *alpha_host);
 int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f, bool wants_factor);
 int gpak_multi_failed_column(gpak_multi *g);
+int gpak_multi_set_kernel(gpak_multi *g, int nterms, const int *kinds, const double *pars, double bias, double white,
+                          double sn2, int dist_mode);
+int gpak_multi_grad_hyb(gpak_multi *g, double *grad, int ng);
 const char *gpak_multi_transport(gpak_multi *g);
 int gpak_multi_stats(gpak_multi *g, int r, gpak_dist_stats *out);
 int gpak_multi_predict(gpak_multi *g, const double *Xte, long M, int d, double *mean, double *var);
@@ -126,6 +129,44 @@ void gpak_build_siginv(const double *e, double *A) {
       for (int k = 0; k < 3; k++) s += R[r + k * 3] * lam[k] * R[c + k * 3];
       A[r + c * 3] = s;
     }
+}
+
+// HybKerns composition -> KernParams (Kernel.cpp:140-154 and the children's parameter lists; shared by gpak_set_kernel
+// and by the distributed paths, which carry the composition as one serialized array: gpak_dev.h GPAK_DIST_HYB)
+int gpak_build_kp(int nterms, const int *kinds, const double *pars, double bias, double white, int dist_mode,
+                  KernParams *out, double *kdiag_out) {
+  KernParams kp;
+  memset(&kp, 0, sizeof(kp));
+  if (nterms < 1 || nterms > GPAK_MAX_TERMS) return GPAK_EINVAL;
+  kp.nterms = nterms;
+  double kdiag = bias + white;
+  const double *p = pars;
+  for (int t = 0; t < nterms; t++) {
+    KernTerm &T = kp.term[t];
+    if (kinds[t] == GPAK_KERN_EXPANS) {
+      gpak_build_siginv(p, T.A);
+      T.a33 = p[7];
+      T.var2 = p[6] * p[6]; T.profile = GPAK_PROFILE_EXPSQRT;
+      p += 8;
+    } else if (kinds[t] == GPAK_KERN_EXP) {   // {Hayper_Euc_Exp, Sigma_Exp}, Kernel.cpp:576-600
+      const double s = 1.0 / p[0];             // mlA: X * hyp^-2 on one side == both sides scaled by 1/hyp
+      T.A[0] = T.A[4] = T.A[8] = T.a33 = s;  // EuclDist treats every input column alike (Kernel.cpp:1356-1362)
+      T.var2 = p[1] * p[1]; T.profile = GPAK_PROFILE_EXPSQRT;
+      p += 2;
+    } else if (kinds[t] == GPAK_KERN_RBF) {   // {Hayper_Euc_RBF, inverseWidth_RBF, Sigma_RBF}, Kernel.cpp:411-428
+      const double s = 1.0 / p[0];
+      T.A[0] = T.A[4] = T.A[8] = T.a33 = s;
+      T.iw = p[1]; T.var2 = p[2] * p[2]; T.profile = GPAK_PROFILE_RBF;
+      p += 3;
+    } else {
+      return GPAK_EINVAL;
+    }
+    kdiag += T.var2;
+  }
+  kp.bias = bias; kp.white = white; kp.mode = dist_mode;
+  *out = kp;
+  if (kdiag_out) *kdiag_out = kdiag;
+  return GPAK_OK;
 }
 
 // pooled mean of X1 u X2 exactly as Kernel.cpp:1391-1392 computes it
@@ -405,36 +446,20 @@ int gpak_set_params(gpak_ctx *ctx, const double *expans, double bias, double sn2
 int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *pars, double bias, double white,
                     double sn2, int dist_mode) {
   if (!ctx || !kinds || !pars || nterms < 1 || nterms > GPAK_MAX_TERMS) return GPAK_EINVAL;
-  if (ctx->multi) { ctx->err = "a multi-GPU context handles the ExpAns(+Bias) composition (gpak_set_params)"; return GPAK_ENOTIMPL; }
   if (dist_mode != GPAK_DIST_EXPANSION && dist_mode != GPAK_DIST_DIRECT) { ctx->err = "bad dist_mode"; return GPAK_EINVAL; }
+  if (ctx->multi) { ctx->sn2 = sn2; GPAK_MULTI_ERR(gpak_multi_set_kernel(ctx->multi, nterms, kinds, pars, bias, white, sn2, dist_mode)); }
   KernParams kp;
-  memset(&kp, 0, sizeof(kp));
-  kp.nterms = nterms;
-  double kdiag = bias + white;
-  const double *p = pars;
-  for (int t = 0; t < nterms; t++) {
-    KernTerm &T = kp.term[t];
-    if (kinds[t] == GPAK_KERN_EXPANS) {
-      gpak_build_siginv(p, T.A);
-      T.a33 = p[7];
-      T.var2 = p[6] * p[6]; T.profile = GPAK_PROFILE_EXPSQRT;
-      memcpy(ctx->expans, p, sizeof(double) * 8);  // the (single) ExpAns child, wherever it sits
-      p += 8;
-    } else if (kinds[t] == GPAK_KERN_EXP) {   // {Hayper_Euc_Exp, Sigma_Exp}, Kernel.cpp:576-600
-      const double s = 1.0 / p[0];             // mlA: X * hyp^-2 on one side == both sides scaled by 1/hyp
-      T.A[0] = T.A[4] = T.A[8] = T.a33 = s;  // EuclDist treats every input column alike (Kernel.cpp:1356-1362)
-      T.var2 = p[1] * p[1]; T.profile = GPAK_PROFILE_EXPSQRT;
-      p += 2;
-    } else if (kinds[t] == GPAK_KERN_RBF) {   // {Hayper_Euc_RBF, inverseWidth_RBF, Sigma_RBF}, Kernel.cpp:411-428
-      const double s = 1.0 / p[0];
-      T.A[0] = T.A[4] = T.A[8] = T.a33 = s;
-      T.iw = p[1]; T.var2 = p[2] * p[2]; T.profile = GPAK_PROFILE_RBF;
-      p += 3;
-    } else { ctx->err = "unknown kernel kind"; return GPAK_EINVAL; }
-    kdiag += T.var2;
-    ctx->kinds[t] = kinds[t];
+  double kdiag = 0.0;
+  int rc = gpak_build_kp(nterms, kinds, pars, bias, white, dist_mode, &kp, &kdiag);
+  if (rc) { ctx->err = "unknown kernel kind"; return rc; }
+  {
+    const double *p = pars;
+    for (int t = 0; t < nterms; t++) {
+      if (kinds[t] == GPAK_KERN_EXPANS) memcpy(ctx->expans, p, sizeof(double) * 8);  // the (single) ExpAns child, wherever it sits
+      p += kinds[t] == GPAK_KERN_EXPANS ? 8 : kinds[t] == GPAK_KERN_EXP ? 2 : 3;
+      ctx->kinds[t] = kinds[t];
+    }
   }
-  kp.bias = bias; kp.white = white; kp.mode = dist_mode;
   ctx->kp = kp;
   ctx->kdiag = kdiag;
   ctx->expans_only = (nterms == 1 && kinds[0] == GPAK_KERN_EXPANS && white == 0.0);
@@ -789,10 +814,7 @@ int gpak_grad(gpak_ctx *ctx, double *g) {
 
 int gpak_grad_hyb(gpak_ctx *ctx, double *g, int ng) {
   if (!ctx || !g) return GPAK_EINVAL;
-  if (ctx->multi) {
-    if (ng != 10) { ctx->err = "a multi-GPU context handles the ExpAns(+Bias) composition: ng must be 10"; return GPAK_EINVAL; }
-    GPAK_MULTI_ERR(gpak_multi_grad(ctx->multi, g));
-  }
+  if (ctx->multi) GPAK_MULTI_ERR(gpak_multi_grad_hyb(ctx->multi, g, ng));
   int rc = ensure_nlz(ctx);
   if (rc) return rc;
   return gpak_grad_impl(ctx, g, ng);

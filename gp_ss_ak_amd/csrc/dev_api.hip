@@ -20,6 +20,15 @@ static DevPoints as_points(const double *u, int cap, int n, int off = 0) {
 static KernParams make_kp(const double *expans, double bias, int mode, const double *mu) {
   KernParams kp;
   memset(&kp, 0, sizeof(kp));
+  if (mode & GPAK_DIST_HYB) {   // a serialized composition (gpak_dev.h)
+    const int nterms = (int)expans[0];
+    int kinds[GPAK_MAX_TERMS] = {0, 0, 0};
+    for (int t = 0; t < GPAK_MAX_TERMS; t++) kinds[t] = (int)expans[1 + t];
+    if (gpak_build_kp(nterms, kinds, expans + 5, bias, expans[4], mode & 0xF, &kp, nullptr) != GPAK_OK) kp.nterms = 0;
+    for (int k = 0; k < 4; k++) kp.mu[k] = mu ? mu[k] : 0.0;
+    kp.d = (mode & GPAK_DIST_D4) ? 4 : 3;
+    return kp;
+  }
   kp.nterms = 1;
   gpak_build_siginv(expans, kp.term[0].A);
   kp.term[0].var2 = expans[6] * expans[6];
@@ -88,6 +97,15 @@ int gpak_dev_transform(void *stream, const double *x, int xs, int n, int cap, co
                        const double *mu, double *u) {
   // always four columns: a 3-D input set carries a zero 4th column (and mu[3] = 0), whose image is 0
   KernParams kp = make_kp(expans, 0.0, GPAK_DIST_DIRECT | GPAK_DIST_D4, mu);
+  DevPoints p = as_points(u, cap, n);
+  gpak_launch_transform((hipStream_t)stream, x, xs, n, kp, p);
+  return status();
+}
+
+int gpak_dev_transform_k(void *stream, const double *x, int xs, int n, int cap, const double *kern, int dist_mode,
+                         const double *mu, double *u) {
+  KernParams kp = make_kp(kern, 0.0, (dist_mode & GPAK_DIST_HYB) | GPAK_DIST_DIRECT | GPAK_DIST_D4, mu);
+  if (kp.nterms < 1) return GPAK_EINVAL;
   DevPoints p = as_points(u, cap, n);
   gpak_launch_transform((hipStream_t)stream, x, xs, n, kp, p);
   return status();

@@ -146,6 +146,9 @@ void fill_hip_engine(gpak_dist_engine &e, HipEngineState *st) {
   e.vec_sum = gpak_dev_vec_sum;
   e.grad_g_rows = gpak_dev_grad_g_rows; e.grad_binv_rows = gpak_dev_grad_binv_rows;
   e.grad_pairs_rows = gpak_dev_grad_pairs_rows;
+  e.fill_rect = gpak_dev_fill_rect; e.solve_rows = gpak_dev_solve_rows; e.update_rect = gpak_dev_update_rect;
+  e.gemv_n_add = gpak_dev_gemv_n_add; e.gemv_t = gpak_dev_gemv_t; e.vec_axpy = gpak_dev_vec_axpy;
+  e.transform_k = gpak_dev_transform_k;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -262,6 +265,9 @@ struct gpak_dist {
   bool have_params = false;
   double expans[8] = {0}, bias = 0, sn2 = 0;
   int mode = GPAK_DIST_DIRECT;
+  bool hyb = false;                         // a general composition (gpak_dist_set_kernel): `kern` is what the engine gets
+  double kern[GPAK_KERN_SERIAL_MAX] = {0};  // serialized: children, kinds, Sigma_White, parameters (gpak_dev.h)
+  double white = 0;
 
   // results
   bool have_result = false;
@@ -276,7 +282,8 @@ struct gpak_dist {
   std::vector<Span> spans;
   bool profile = true;
 
-  int kmode() const { return mode | (d == 4 ? GPAK_DIST_D4 : 0); }   // what the kernel-evaluating engine calls get
+  int kmode() const { return mode | (d == 4 ? GPAK_DIST_D4 : 0) | (hyb ? GPAK_DIST_HYB : 0); }   // what the engine calls get
+  const double *kpars() const { return hyb ? kern : expans; }
   int width(int b) const { return std::min(nb, Np - b * nb); }
   int start(int b) const { return b * nb; }
   int owner(int b) const { return b % P; }
@@ -575,7 +582,8 @@ int gpak_dist_set_train(gpak_dist *h, const double *X, const double *y, int N, i
   for (int b = 0; b < h->nJ; b++) if (h->owner(b) == h->rank) h->owned.push_back(b);
   const size_t Np = h->Np;
   auto dalloc = [&](size_t n) { return (double *)E.alloc(E.self, sizeof(double) * (n ? n : 1)); };
-  h->x_soa = dalloc(4 * Np); h->y = dalloc(Np); h->u = dalloc(5 * Np);   // four raw columns, the 4th zero for d = 3
+  h->x_soa = dalloc(4 * Np); h->y = dalloc(Np);   // four raw columns, the 4th zero for d = 3
+  h->u = dalloc(5 * GPAK_MAX_TERMS * Np);          // 5 arrays per child of the composition
   h->local = dalloc(std::max<size_t>(1, h->owned.size()) * nb * h->ld);
   h->scratch = dalloc(64 * Np); h->small = dalloc(16); h->alpha = dalloc(Np);
   h->fwd_x = dalloc(Np); h->fwd_z = dalloc(Np); h->rhs = dalloc(Np); h->f = dalloc(Np);
@@ -624,8 +632,33 @@ int gpak_dist_set_params(gpak_dist *h, const double *expans, double bias, double
   if (dist_mode != GPAK_DIST_EXPANSION && dist_mode != GPAK_DIST_DIRECT) { h->err = "bad dist_mode"; return GPAK_EINVAL; }
   memcpy(h->expans, expans, sizeof(double) * 8);
   h->bias = bias; h->sn2 = sn2; h->mode = dist_mode;
+  h->hyb = false; h->white = 0.0;
   h->have_params = true;
   h->have_result = false;   // GP_Utils.cpp:132-133: always invalidates
+  return GPAK_OK;
+}
+
+int gpak_dist_set_kernel(gpak_dist *h, int nterms, const int *kinds, const double *pars, double bias, double white,
+                         double sn2, int dist_mode) {
+  if (!h || !kinds || !pars || nterms < 1 || nterms > GPAK_MAX_TERMS) return GPAK_EINVAL;
+  if (dist_mode != GPAK_DIST_EXPANSION && dist_mode != GPAK_DIST_DIRECT) { h->err = "bad dist_mode"; return GPAK_EINVAL; }
+  if (!h->E.transform_k || !h->E.vec_axpy) { h->err = "the engine has no transform_k / vec_axpy entry"; return GPAK_ENOTIMPL; }
+  memset(h->kern, 0, sizeof(h->kern));
+  h->kern[0] = nterms; h->kern[4] = white;
+  int np = 0;
+  for (int t = 0; t < nterms; t++) {
+    if (kinds[t] != GPAK_KERN_EXPANS && kinds[t] != GPAK_KERN_EXP && kinds[t] != GPAK_KERN_RBF) { h->err = "unknown kernel kind"; return GPAK_EINVAL; }
+    h->kern[1 + t] = kinds[t];
+    const int k = kinds[t] == GPAK_KERN_EXPANS ? 8 : kinds[t] == GPAK_KERN_EXP ? 2 : 3;
+    if (kinds[t] == GPAK_KERN_EXPANS) memcpy(h->expans, pars + np, sizeof(double) * 8);
+    np += k;
+  }
+  if (5 + np > GPAK_KERN_SERIAL_MAX) return GPAK_EINVAL;
+  memcpy(h->kern + 5, pars, sizeof(double) * np);
+  h->bias = bias; h->white = white; h->sn2 = sn2; h->mode = dist_mode;
+  h->hyb = true;
+  h->have_params = true;
+  h->have_result = false;
   return GPAK_OK;
 }
 
@@ -809,9 +842,10 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
       const double mX1 = n / (n + n) * h->xsum[k] / n;
       mu[k] = n / (n + n) * h->xsum[k] / n + mX1;
     }
-    DCHK(E.transform(h->s_bulk, h->x_soa, Np, N, h->cap, h->expans, mu, h->u));
+    if (h->hyb) DCHK(E.transform_k(h->s_bulk, h->x_soa, Np, N, h->cap, h->kern, h->kmode(), mu, h->u));
+    else DCHK(E.transform(h->s_bulk, h->x_soa, Np, N, h->cap, h->expans, mu, h->u));
     for (int b : h->owned)
-      DCHK(E.fill_b(h->s_bulk, h->u, h->cap, N, Np, h->start(b), h->width(b), h->expans, h->bias, h->sn2, h->kmode(),
+      DCHK(E.fill_b(h->s_bulk, h->u, h->cap, N, Np, h->start(b), h->width(b), h->kpars(), h->bias, h->sn2, h->kmode(),
                     h->blk(b), h->ld));
   }
   DCHK(E.vec_scale(h->s_bulk, Np, h->y, 1.0 / h->sn2, h->rhs));            // rhs = y / sn2
@@ -843,7 +877,9 @@ int gpak_dist_nlz(gpak_dist *h, double *nlz) {
   DCHK(E.zero(E.self, h->s_bulk, h->f, sizeof(double) * Np));
   const size_t tk0 = h->time_event(h->s_bulk);
   if (i1 > i0)
-    DCHK(E.kmatvec(h->s_bulk, h->u, h->cap, N, i0, i1, h->alpha, h->expans, h->bias, h->kmode(), h->scratch, h->f));
+    DCHK(E.kmatvec(h->s_bulk, h->u, h->cap, N, i0, i1, h->alpha, h->kpars(), h->bias, h->kmode(), h->scratch, h->f));
+  // Kern_White is the diagonal Sigma_White I (Kernel.cpp:256-263): its share of K alpha, once (rank 0's partial sum)
+  if (h->hyb && h->white != 0.0 && h->rank == 0) DCHK(E.vec_axpy(h->s_bulk, N, h->white, h->alpha, h->f));
   const size_t tk1 = h->time_event(h->s_bulk);
   DCHK(hop_in(h));
   DCHK(T.allreduce_sum(T.self, h->s_comm, h->f, (size_t)Np));
@@ -908,6 +944,7 @@ int gpak_dist_get_alpha(gpak_dist *h, double *alpha_host) {
 int gpak_dist_grad(gpak_dist *h, double *g) {
   if (!h || !g) return GPAK_EINVAL;
   double v;
+  if (h->hyb) { h->err = "gpak_dist_grad handles the ExpAns(+Bias) composition"; return GPAK_ENOTIMPL; }
   int rc = gpak_dist_nlz(h, &v);   // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
   if (rc) return rc;
   set_device(h);

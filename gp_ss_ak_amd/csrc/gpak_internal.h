@@ -87,6 +87,8 @@ struct GpakTuning {
                                //                    are skewed by this many 256-byte units (0: powers of two, as in round 2)
 };
 const GpakTuning &gpak_tuning();
+int gpak_build_kp(int nterms, const int *kinds, const double *pars, double bias, double white, int dist_mode,
+                  KernParams *out, double *kdiag_out);
 
 struct gpak_multi;   // multi.hip: one process driving several GPUs (gpak_create_multi)
 

@@ -175,6 +175,10 @@ struct gpak_multi {
   bool have_params = false, general_kernel = false;
   double expans[8] = {0}, bias = 0, sn2 = 0;
   int dist_mode = GPAK_DIST_DIRECT;
+  // a general HybKerns composition (gpak_set_kernel on the group): kinds / parameters / Kern_White as given
+  int nterms = 1, kinds[GPAK_MAX_TERMS] = {0, 0, 0};
+  std::vector<double> pars;
+  double white = 0;
   std::vector<char> replica_train_ok, replica_params_ok;
   int nb = 512;
   std::string err;                   // written by the caller's thread only, after run(): see fail()
@@ -241,7 +245,8 @@ static int ensure_replica(gpak_multi *g, int r) {
   }
   if (!g->replica_params_ok[r]) {
     if (!g->have_params) return g->fail(r, GPAK_ESTATE, "no parameters (gpak_set_params)");
-    int rc = gpak_set_params(c, g->expans, g->bias, g->sn2, g->dist_mode);
+    int rc = g->general_kernel ? gpak_set_kernel(c, g->nterms, g->kinds, g->pars.data(), g->bias, g->white, g->sn2, g->dist_mode)
+                               : gpak_set_params(c, g->expans, g->bias, g->sn2, g->dist_mode);
     if (rc) return g->fail(r, rc, gpak_last_error(c));
     g->replica_params_ok[r] = 1;
     g->replica_factor_ok[r] = 0;
@@ -395,11 +400,36 @@ int gpak_multi_set_train(gpak_multi *g, const double *X, const double *y, int N,
 int gpak_multi_set_params(gpak_multi *g, const double *expans, double bias, double sn2, int dist_mode) {
   memcpy(g->expans, expans, sizeof(double) * 8);
   g->bias = bias; g->sn2 = sn2; g->dist_mode = dist_mode; g->have_params = true;
+  g->general_kernel = false; g->white = 0.0;
   std::fill(g->replica_params_ok.begin(), g->replica_params_ok.end(), 0);
   std::fill(g->replica_factor_ok.begin(), g->replica_factor_ok.end(), 0);
   g->factor_current = false;
   for (int r = 0; r < g->P; r++) {
     int rc = gpak_dist_set_params(g->ranks[r], expans, bias, sn2, dist_mode);
+    if (rc) { g->err = gpak_dist_last_error(g->ranks[r]); return rc; }
+  }
+  return GPAK_OK;
+}
+
+// HybKerns of other children on the group (gpak_set_kernel): logLikelihood / alpha distributed with the serialized
+// composition, prediction and solve_chol on the imported factor, the children's gradients on device 0 (gpak_multi_grad_hyb)
+int gpak_multi_set_kernel(gpak_multi *g, int nterms, const int *kinds, const double *pars, double bias, double white,
+                          double sn2, int dist_mode) {
+  int np = 0;
+  for (int t = 0; t < nterms; t++) {
+    g->kinds[t] = kinds[t];
+    if (kinds[t] == GPAK_KERN_EXPANS) memcpy(g->expans, pars + np, sizeof(double) * 8);
+    np += kinds[t] == GPAK_KERN_EXPANS ? 8 : kinds[t] == GPAK_KERN_EXP ? 2 : 3;
+  }
+  g->nterms = nterms;
+  g->pars.assign(pars, pars + np);
+  g->bias = bias; g->white = white; g->sn2 = sn2; g->dist_mode = dist_mode; g->have_params = true;
+  g->general_kernel = true;
+  std::fill(g->replica_params_ok.begin(), g->replica_params_ok.end(), 0);
+  std::fill(g->replica_factor_ok.begin(), g->replica_factor_ok.end(), 0);
+  g->factor_current = false;
+  for (int r = 0; r < g->P; r++) {
+    int rc = gpak_dist_set_kernel(g->ranks[r], nterms, kinds, pars, bias, white, sn2, dist_mode);
     if (rc) { g->err = gpak_dist_last_error(g->ranks[r]); return rc; }
   }
   return GPAK_OK;
@@ -443,6 +473,7 @@ int gpak_multi_alpha(gpak_multi *g, double *alpha_host) {
 
 // GP_utils::GradLL on the group: B^-1 by row blocks over the ranks (gpak_dist_grad)
 int gpak_multi_grad(gpak_multi *g, double *grad10) {
+  if (g->general_kernel) { g->err = "gpak_grad handles the ExpAns(+Bias) composition only (use gpak_grad_hyb)"; return GPAK_ENOTIMPL; }
   double v;
   int rc = gpak_multi_nlz(g, &v, nullptr, nullptr, nullptr);   // GradLL re-enters logLikelihood(): GP_Utils.cpp:1173-1174
   if (rc) return rc;
@@ -454,6 +485,17 @@ int gpak_multi_grad(gpak_multi *g, double *grad10) {
   if (rc) return rc;
   memcpy(grad10, gs[0].data(), sizeof(double) * 10);
   return GPAK_OK;
+}
+
+// GradLL of any composition on a group: ExpAns(+Bias) is distributed (gpak_multi_grad); other compositions take the
+// children's getGradients on device 0 from the DISTRIBUTED factor (imported into the replica, nothing is factored again)
+int gpak_multi_on_replica0(gpak_multi *g, const std::function<int(gpak_ctx *)> &f, bool wants_factor);
+int gpak_multi_grad_hyb(gpak_multi *g, double *grad, int ng) {
+  if (!g->general_kernel) {
+    if (ng != 10) { g->err = "the ExpAns(+Bias) composition has 10 gradient entries"; return GPAK_EINVAL; }
+    return gpak_multi_grad(g, grad);
+  }
+  return gpak_multi_on_replica0(g, [&](gpak_ctx *c) { return gpak_grad_hyb(c, grad, ng); }, true);
 }
 
 int gpak_multi_stats(gpak_multi *g, int r, gpak_dist_stats *out) {

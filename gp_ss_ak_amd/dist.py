@@ -67,6 +67,8 @@ ENGINE_FIELDS = [
     ("gemv_n_add", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp)),
     ("gemv_t", _F(C.c_int, _vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp)),
     ("vec_axpy", _F(C.c_int, _vp, C.c_int, C.c_double, _vp, _vp)),
+    # a serialized HybKerns composition (gpak_dev.h GPAK_DIST_HYB)
+    ("transform_k", _F(C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, _vp)),
 ]
 
 
@@ -97,7 +99,7 @@ class Stats(C.Structure):
 
 
 DIST_SYMBOLS = ["gpak_dist_create", "gpak_dist_destroy", "gpak_dist_last_error", "gpak_dist_rccl_unique_id",
-                "gpak_dist_init_rccl", "gpak_dist_selfcheck", "gpak_dist_set_train", "gpak_dist_set_params",
+                "gpak_dist_init_rccl", "gpak_dist_selfcheck", "gpak_dist_set_train", "gpak_dist_set_params", "gpak_dist_set_kernel",
                 "gpak_dist_nlz", "gpak_dist_nlz_terms", "gpak_dist_grad", "gpak_dist_get_alpha", "gpak_dist_get_stats",
                 "gpak_dist_failed_column", "gpak_group_rank_stats", "gpak_create_multi_with_engines",
                 "gpak_grid_create", "gpak_grid_destroy", "gpak_grid_last_error", "gpak_grid_init_rccl", "gpak_grid_set_train",
@@ -120,6 +122,7 @@ def _load():
     lib.gpak_dist_selfcheck.argtypes = [_vp, C.POINTER(C.c_int)]
     lib.gpak_dist_set_train.argtypes = [_vp, _dp, _dp, C.c_int, C.c_int, C.c_int]
     lib.gpak_dist_set_params.argtypes = [_vp, _dp, C.c_double, C.c_double, C.c_int]
+    lib.gpak_dist_set_kernel.argtypes = [_vp, C.c_int, C.POINTER(C.c_int), _dp, C.c_double, C.c_double, C.c_double, C.c_int]
     lib.gpak_dist_nlz.argtypes = [_vp, _dp]
     lib.gpak_dist_nlz_terms.argtypes = [_vp, _dp, _dp, _dp]
     lib.gpak_dist_get_alpha.argtypes = [_vp, _dp]
@@ -274,6 +277,13 @@ class DistRank:
     def set_params(self, expans, bias, sn2, dist_mode=1):
         e = np.ascontiguousarray(expans, dtype=np.float64)
         self._check(self._lib.gpak_dist_set_params(self._h, e.ctypes.data_as(_dp), float(bias), float(sn2), int(dist_mode)))
+
+    def set_kernel(self, terms, bias, white, sn2, dist_mode=1):
+        """General HybKerns composition: terms = [(kind, [parameters in the reference's order]), ...] (gpak.KERN_*)."""
+        kinds = (C.c_int * len(terms))(*[int(k) for k, _ in terms])
+        pars = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64) for _, p in terms]))
+        self._check(self._lib.gpak_dist_set_kernel(self._h, len(terms), kinds, pars.ctypes.data_as(_dp), float(bias),
+                                                   float(white), float(sn2), int(dist_mode)))
 
     def nlz(self):
         v = C.c_double()

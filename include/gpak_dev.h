@@ -25,6 +25,13 @@ extern "C" {
  * bit-identical to the 3-column arithmetic), mu has four entries, and the calls that evaluate the kernel take
  * GPAK_DIST_D4 OR-ed into dist_mode to select the 4-coordinate distance. */
 #define GPAK_DIST_D4 0x10
+/* A general HybKerns composition (Kernel.cpp:140-154: up to three stationary children + Kern_Bias + Kern_White) travels
+ * through the same calls as ONE serialized array in place of `expans`, announced by GPAK_DIST_HYB in dist_mode:
+ *   kern[0] = number of children (1..3), kern[1..3] = their kinds (GPAK_KERN_* of gpak.h), kern[4] = Sigma_White,
+ *   kern[5 ...] = the children's parameter lists concatenated in the reference's order (ExpAns 8, Exp 2, RBF 3 values).
+ * `bias` stays its own argument.  The transformed points then hold 5 arrays PER CHILD (u must have 5 * 3 * cap doubles). */
+#define GPAK_DIST_HYB 0x20
+#define GPAK_KERN_SERIAL_MAX 32
 
 /* u = (x - mu) * sigInv for the N points, SoA: u is 5*cap doubles {u0[cap],u1[cap],u2[cap],|u|^2[cap],u3[cap]}
  * (u3 = transformed 4th input column of the context-level API; zero here, the distributed path is 3-D).
@@ -135,6 +142,10 @@ int gpak_dev_update_rect(void *stream, const double *A, long lda, const double *
 int gpak_dev_gemv_n_add(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y);
 int gpak_dev_gemv_t(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y);
 int gpak_dev_vec_axpy(void *stream, int n, double a, const double *x, double *y);
+/* gpak_dev_transform for a serialized composition (dist_mode carries GPAK_DIST_HYB [| GPAK_DIST_D4]); without
+ * GPAK_DIST_HYB `kern` is the plain 8-value ExpAns list and the call equals gpak_dev_transform */
+int gpak_dev_transform_k(void *stream, const double *x, int xs, int n, int cap, const double *kern, int dist_mode,
+                         const double *mu, double *u);
 
 /* A HIP stream that may not use the first skip_cus compute units (hipExtStreamCreateWithCUMask): the bulk
  * updates of a rank run there, so that the serial panel chain (potrf128, the small panel products) always finds

@@ -101,6 +101,10 @@ typedef struct gpak_dist_engine {
   int (*gemv_n_add)(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y); /* y += A x   */
   int (*gemv_t)(void *stream, const double *A, long ld, int nrows, int W, const double *x, double *y);     /* y  = A^T x */
   int (*vec_axpy)(void *stream, int n, double a, const double *x, double *y);                              /* y += a x   */
+  /* transform for a serialized HybKerns composition (gpak_dev.h GPAK_DIST_HYB): `kern` in place of expans, the flags in
+   * dist_mode; fill_b / kmatvec / fill_rect receive the same array and flags through their expans / dist_mode arguments */
+  int (*transform_k)(void *stream, const double *x, int xs, int n, int cap, const double *kern, int dist_mode,
+                     const double *mu, double *u);
 } gpak_dist_engine;
 
 /* Collectives on device buffers, enqueued on `stream` (an engine stream) in call order; every rank calls them in
@@ -147,6 +151,11 @@ int gpak_dist_selfcheck(gpak_dist *h, int *flags_out);
 int gpak_dist_set_train(gpak_dist *h, const double *X, const double *y, int N, int d, int nb);
 /* GP_utils::set_GP_Pars (GP_Utils.cpp:130-157), replicated: as gpak_set_params */
 int gpak_dist_set_params(gpak_dist *h, const double *expans, double bias, double sn2, int dist_mode);
+/* A general HybKerns composition, replicated: as gpak_set_kernel of gpak.h (kinds / concatenated parameters / Kern_Bias /
+ * Kern_White).  logLikelihood and alpha are distributed as for ExpAns(+Bias); gpak_dist_grad is then GPAK_ENOTIMPL (a
+ * gpak_create_multi group forms the children's gradients on device 0 from the distributed factor). */
+int gpak_dist_set_kernel(gpak_dist *h, int nterms, const int *kinds, const double *pars, double bias, double white,
+                         double sn2, int dist_mode);
 /* GP_utils::logLikelihood (GP_Utils.cpp:1138-1162): fill + factor + solves + f = K alpha + reductions.
  * Same value on every rank; quiet NaN with GPAK_ENOTPD on Chol_fail. */
 int gpak_dist_nlz(gpak_dist *h, double *nlz);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--grad", type=int, default=0)
     ap.add_argument("--corrupt", type=int, default=0)
+    ap.add_argument("--hyb", type=int, default=0, help="1: ExpAns + Exp + RBF + Bias + White through gpak_dist_set_kernel")
     ap.add_argument("--d", type=int, default=3, help="input columns (4: with a rock-type column)")
     ap.add_argument("--grid", default="", help="PrxPc: the row-block x column-block layout (gpak_grid_*)")
     ap.add_argument("--out", required=True)
@@ -58,7 +59,10 @@ def main():
     for s in range(a.steps):          # repeated steps reuse the receive buffers: the second one must not race
         e = list(synth.DEFAULT_EXPANS)
         e[1] += 0.01 * (a.steps - 1 - s)
-        gp.set_params(e, synth.DEFAULT_BIAS, sn2, a.mode)
+        if a.hyb:
+            gp.set_kernel([(0, e), (1, [0.5, 0.9]), (2, [0.5, 0.9, 0.5])], synth.DEFAULT_BIAS, 0.10, sn2, a.mode)
+        else:
+            gp.set_params(e, synth.DEFAULT_BIAS, sn2, a.mode)
         nlz = gp.nlz()
     st = gp.stats()
     res.update({"nlz": nlz, "stats": st})

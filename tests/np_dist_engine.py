@@ -62,10 +62,11 @@ class NumpyDistEngine:
             ms[0] = 0.0
 
         def transform(st, x, xs, n, cap, expans, mu, u):
-            eng.transform(_t(x, 4 * xs), xs, n, cap, [expans[i] for i in range(8)], [mu[i] for i in range(4)], _t(u, 5 * cap))
+            eng.transform(_t(x, 4 * xs), xs, n, cap, [expans[i] for i in range(8)], [mu[i] for i in range(4)], _t(u, 15 * cap))
 
         def fill_b(st, u, cap, n, Np, J, W, expans, bias, sn2, mode, blk, ld):
-            eng.fill_b(_t(u, 5 * cap), cap, n, Np, J, W, [expans[i] for i in range(8)], bias, sn2, mode, _t(blk, W * ld), ld)
+            eng.fill_b(_t(u, 15 * cap), cap, n, Np, J, W, [expans[i] for i in range(32 if mode & 0x20 else 8)], bias, sn2, mode,
+                       _t(blk, W * ld), ld)
 
         def factor_panel(st, blk, ld, Np, J, W, inv, info):
             # rows J .. Np of the block column through a strided view: `blk` may be a VIRTUAL base (the grid layout passes
@@ -141,7 +142,7 @@ class NumpyDistEngine:
             _arr(out, 1)[0] = float(np.log(np.diag(M)[:nc]).sum()) if nc else 0.0
 
         def kmatvec(st, u, cap, n, i0, i1, w, expans, bias, mode, scratch, out):
-            eng.kmatvec(_t(u, 5 * cap), cap, n, i0, i1, _t(w, cap), [expans[i] for i in range(8)], bias, mode, None,
+            eng.kmatvec(_t(u, 15 * cap), cap, n, i0, i1, _t(w, cap), [expans[i] for i in range(32 if mode & 0x20 else 8)], bias, mode, None,
                         _t(out, cap))
 
         def nlz_terms(st, N, y, f, alpha, sn2, out):
@@ -243,7 +244,7 @@ class NumpyDistEngine:
 
         # ---- the row-block x column-block layout (gpak_grid_*): rectangular pieces of LOCAL storage -------------
         def fill_rect(st, u, cap, n, row0, nrows, col0, ncols, expans, bias, sn2, mode, dst, ld):
-            un = _arr(u, 5 * cap).reshape(5, cap)
+            un = _arr(u, 15 * cap).reshape(15, cap)
             D = _strided(dst, nrows, ncols, ld)
             D[:] = 0.0
             r1, c1 = min(n, row0 + nrows), min(n, col0 + ncols)
@@ -283,6 +284,10 @@ class NumpyDistEngine:
         def vec_axpy(st, n, a, x, y):
             _arr(y, n)[:] += a * _arr(x, n)
 
+        def transform_k(st, x, xs, n, cap, kern, mode, mu, u):
+            eng.transform_k(_t(x, 4 * xs), xs, n, cap, [kern[i] for i in range(32)], mode, [mu[i] for i in range(4)],
+                            _t(u, 15 * cap))
+
         def vec_scale(st, n, a, s, out):
             _arr(out, n)[:] = _arr(a, n) * s
 
@@ -301,6 +306,7 @@ class NumpyDistEngine:
             "vec_sum": ok(vec_sum), "grad_g_rows": ok(grad_g_rows), "grad_binv_rows": ok(grad_binv_rows),
             "grad_pairs_rows": ok(grad_pairs_rows), "fill_rect": ok(fill_rect), "solve_rows": ok(solve_rows),
             "update_rect": ok(update_rect), "gemv_n_add": ok(gemv_n_add), "gemv_t": ok(gemv_t), "vec_axpy": ok(vec_axpy),
+            "transform_k": ok(transform_k),
         }
         self._keep = {name: F[name](fn) for name, fn in impl.items()}
         self.table = gd.Engine(None, *[self._keep[name] for name, _ in gd.ENGINE_FIELDS[1:]])

@@ -35,14 +35,64 @@ class NumpyEngine:
         mu = list(mu) + [0.0] * (4 - len(mu))
         U = (X4[:, :3] - np.asarray(mu[:3])[None, :]) @ self._A(expans)
         u3 = expans[7] * (X4[:, 3] - mu[3])
-        un = u.numpy().reshape(5, cap)
-        un[:] = 0
+        un = self._un(u, cap)
+        un[:5] = 0
         un[:3, :n] = U.T
         un[4, :n] = u3
         un[3, :n] = (U * U).sum(1) + u3 * u3
 
     @staticmethod
-    def _kfun(un, rows, cols, expans, bias, mode):
+    def decode_kern(kern):
+        """gpak_dev.h GPAK_DIST_HYB serialization -> (terms [(kind, params)], white)."""
+        n = int(kern[0])
+        kinds = [int(kern[1 + t]) for t in range(n)]
+        terms, p = [], 5
+        for k in kinds:
+            m = {0: 8, 1: 2, 2: 3}[k]
+            terms.append((k, [float(kern[p + i]) for i in range(m)]))
+            p += m
+        return terms, float(kern[4])
+
+    def transform_k(self, x_soa, xs, n, cap, kern, mode, mu, u):
+        """5 arrays per child: ExpAns -> (x - mu) sigInv and InversewidthR * x3; Exp / RBF -> every column / Hayper."""
+        if not mode & 0x20:
+            return self.transform(x_soa, xs, n, cap, kern, mu, u)
+        terms, _ = self.decode_kern(kern)
+        X4 = x_soa.numpy().reshape(4, xs)[:, :n].T
+        mu = np.asarray(list(mu) + [0.0] * (4 - len(mu)))
+        un = self._un(u, cap)[:15].reshape(3, 5, cap)
+        un[:] = 0
+        for t, (kind, p) in enumerate(terms):
+            if kind == 0:
+                U3 = (X4[:, :3] - mu[None, :3]) @ self._A(p)
+                u3 = p[7] * (X4[:, 3] - mu[3])
+            else:
+                U3 = (X4[:, :3] - mu[None, :3]) / p[0]
+                u3 = (X4[:, 3] - mu[3]) / p[0]
+            un[t, :3, :n] = U3.T
+            un[t, 4, :n] = u3
+            un[t, 3, :n] = (U3 * U3).sum(1) + u3 * u3
+
+    @classmethod
+    def _kfun(cls, un, rows, cols, expans, bias, mode):
+        if mode & 0x20:                   # GPAK_DIST_HYB: `expans` is the serialized composition, un has 5 arrays per child
+            terms, _white = cls.decode_kern(expans)
+            cap = un.shape[1]
+            unt = un[:15].reshape(3, 5, cap)
+            K = np.full((len(range(*rows.indices(cap))), len(range(*cols.indices(cap)))), float(bias))
+            for t, (kind, p) in enumerate(terms):
+                sel = [0, 1, 2, 4] if mode & 0x10 else [0, 1, 2]
+                P, Q = unt[t][sel][:, rows].T, unt[t][sel][:, cols].T
+                if (mode & 0xF) == 1:
+                    D2 = ((P[:, None, :] - Q[None, :, :]) ** 2).sum(-1)
+                else:
+                    D2 = unt[t][3, rows][:, None] + unt[t][3, cols][None, :] - 2 * P @ Q.T
+                    D2[D2 < 0] = 0
+                if kind == 2:
+                    K += p[2] ** 2 * np.exp(-0.5 * p[1] * D2)
+                else:
+                    K += (p[6] if kind == 0 else p[1]) ** 2 * np.exp(-np.sqrt(D2))
+            return K
         d4 = bool(mode & 0x10)            # GPAK_DIST_D4: the transformed 4th column takes part in the distance
         mode &= 0xF
         sel = [0, 1, 2, 4] if d4 else [0, 1, 2]
@@ -54,15 +104,23 @@ class NumpyEngine:
             D2[D2 < 0] = 0
         return expans[6] ** 2 * np.exp(-np.sqrt(D2)) + bias
 
+    @staticmethod
+    def _un(u, cap):
+        """the transformed points as (arrays x cap): 5 arrays, or 15 when the buffer holds a composition's three children"""
+        a = u.numpy()
+        rows = a.size // cap
+        return a[:rows * cap].reshape(rows, cap)
+
     def fill_b(self, u, cap, n, Np, J, W, expans, bias, sn2, mode, blk, ld):
-        un = u.numpy().reshape(5, cap)
+        un = self._un(u, cap)
         M = blk.numpy().reshape(W, ld).T  # (ld x W) column-major view
         M[:Np, :] = 0
         nc = max(0, min(W, n - J))
         if nc > 0:
             M[:n, :nc] = self._kfun(un, slice(0, n), slice(J, J + nc), expans, bias, mode) / sn2
+        white = self.decode_kern(expans)[1] if mode & 0x20 else 0.0     # Kern_White: Sigma_White on the diagonal
         for c in range(W):
-            M[J + c, c] += 1.0
+            M[J + c, c] += 1.0 + (white / sn2 if J + c < n else 0.0)
 
     def factor_panel(self, blk, ld, Np, J, W, inv, info):
         M = blk.numpy().reshape(W, ld).T
@@ -150,7 +208,7 @@ class NumpyEngine:
         out[0] = float(np.log(np.diag(M[J:J + nc, :nc])).sum()) if nc else 0.0
 
     def kmatvec(self, u, cap, n, i0, i1, w, expans, bias, mode, scratch, out):
-        un = u.numpy().reshape(5, cap)
+        un = self._un(u, cap)
         K = self._kfun(un, slice(i0, i1), slice(0, n), expans, bias, mode)
         out.numpy()[:n] = w.numpy()[i0:i1] @ K
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_functions() + header_functions("gpak_dev.h"):
         assert hasattr(lib, name), name
-    assert len(header_functions("gpak_dev.h")) == 29       # the device-pointer level API of the multi-GPU path
+    assert len(header_functions("gpak_dev.h")) == 30       # the device-pointer level API of the multi-GPU path
     from gp_ss_ak_amd import dist
     dist_fns = header_functions("gpak_dist.h")             # the C++ multi-GPU schedule
     assert sorted(dist.DIST_SYMBOLS) == dist_fns

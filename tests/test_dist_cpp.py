@@ -33,7 +33,7 @@ def free_port():
 
 
 def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=900, grad=0, corrupt=0, env=None, grid=None,
-              ncols=3):
+              ncols=3, hyb=0):
     port = free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
@@ -48,6 +48,8 @@ def run_world(world, n, nb, engine="numpy", mode=1, sn2=None, steps=1, timeout=9
                 cmd += ["--grid", f"{grid[0]}x{grid[1]}"]
             if ncols != 3:
                 cmd += ["--d", str(ncols)]
+            if hyb:
+                cmd += ["--hyb", "1"]
             penv = dict(os.environ, OMP_NUM_THREADS="2", **(env or {}))
             procs.append(subprocess.Popen(cmd, env=penv, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
@@ -237,6 +239,71 @@ def test_four_column_inputs_on_a_multi_gpu_context(orc):
         mean, var = g.posteriorMeanVar(Xt)
         mo, vo = orc.predict(X, Xt, e, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, alpha, L, orc.DIST_DIRECT, 0)
         assert np.abs(mean - mo).max() <= 1e-8 * np.abs(mo).max() and np.abs(var - vo).max() <= 1e-8 * np.abs(vo).max()
+    finally:
+        g.close()
+
+
+HYB_TERMS = [(0, list(synth.DEFAULT_EXPANS)), (1, [0.5, 0.9]), (2, [0.5, 0.9, 0.5])]
+
+
+@pytest.mark.parametrize("world,n,nb,ncols", [(2, 500, 128, 3), (3, 800, 256, 3), (2, 600, 128, 4)])
+def test_other_compositions_on_the_distributed_path(orc, world, n, nb, ncols):
+    """HybKerns{ExpAns, Exp, RBF} + Bias + White on more than one rank (gpak_dist_set_kernel: the composition travels to the
+    engine as one serialized array): nlZ, its terms and alpha against the oracle's gram_hyb; the fixed-length gradient is
+    refused on that path."""
+    res = run_world(world, n, nb, hyb=1, ncols=ncols)
+    X, y = (synth.drillholes4(n) if ncols == 4 else synth.drillholes(n))
+    K = orc.gram_hyb(X, X, HYB_TERMS, synth.DEFAULT_BIAS, 0.10, 1)
+    info, alpha, _ = orc.nlz_lean(K, y, synth.DEFAULT_SN2)
+    for r in res:
+        assert abs(r["nlz"] - info.nlz) <= 1e-9 * abs(info.nlz), (r["nlz"], info.nlz)
+        assert abs(r["logdet"] - info.logdet) <= 1e-10 * abs(info.logdet)
+        assert np.abs(np.array(r["alpha"]) - alpha).max() <= 1e-8 * np.abs(alpha).max()
+
+
+@pytest.mark.gpu
+def test_other_compositions_on_a_multi_gpu_context(orc):
+    """The same through gpak_create_multi (three ranks on this box's GPU): gpak_set_kernel on the group, nlZ / alpha
+    distributed, the sharded prediction and the children's gradients (device 0) on the distributed factor."""
+    import scipy.linalg as sl
+    from gp_ss_ak_amd import gpak
+    n, M = 1400, 200
+    X, y = synth.drillholes(n)
+    Xt = synth.test_points(M)
+    E = np.array(synth.DEFAULT_EXPANS)
+    terms = [(gpak.KERN_EXPANS, E), (gpak.KERN_EXP, [0.5, 0.9]), (gpak.KERN_RBF, [0.5, 0.9, 0.5])]
+    g = gpak.Gpak(devices=[0, 0, 0])
+    try:
+        g.set_train(X, y)
+        g.set_kernel(terms, synth.DEFAULT_BIAS, 0.10, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
+        Ko = orc.gram_hyb(X, X, terms, synth.DEFAULT_BIAS, 0.10, orc.DIST_DIRECT)
+        info, alpha, _ = orc.nlz_lean(Ko, y, synth.DEFAULT_SN2)
+        assert abs(g.logLikelihood() - info.nlz) <= 1e-9 * abs(info.nlz)
+        assert np.abs(g.solve_alpha() - alpha).max() <= 1e-8 * np.abs(alpha).max()
+        mean, var = g.posteriorMeanVar(Xt)
+        kX = orc.gram_hyb(X, Xt, terms, synth.DEFAULT_BIAS, 0.10, orc.DIST_DIRECT)
+        cf = sl.cho_factor(Ko + synth.DEFAULT_SN2 * np.eye(n), lower=True)
+        kD = E[6] ** 2 + 0.9 ** 2 + 0.5 ** 2 + synth.DEFAULT_BIAS + 0.10
+        vo = np.maximum(kD - np.einsum("ij,ij->j", kX, sl.cho_solve(cf, kX)), 0) + synth.DEFAULT_SN2
+        assert np.abs(mean - kX.T @ alpha).max() <= 1e-8 * np.abs(kX.T @ alpha).max()
+        assert np.abs(var - vo).max() <= 1e-8 * np.abs(vo).max()
+        with pytest.raises(gpak.GpakError) as ei:
+            g.GradLL()
+        assert ei.value.status == gpak.ENOTIMPL
+        assert g.timing()["evaluations"] == 1
+        # without the White child the reference has gradients for every child: on device 0, from the distributed factor
+        g.set_kernel(terms, synth.DEFAULT_BIAS, 0.0, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
+        gg = g.GradLL_hyb(8 + 2 + 3 + 2)
+        K0 = orc.gram_hyb(X, X, terms, synth.DEFAULT_BIAS, 0.0, orc.DIST_DIRECT)
+        i0, a0, L0 = orc.nlz_lean(K0, y, synth.DEFAULT_SN2)
+        go = orc.grad_hyb(X, y, K0, L0, a0, terms, True, synth.DEFAULT_SN2, orc.DIST_DIRECT)
+        assert np.abs(gg - go).max() <= 1e-8 * np.abs(go).max()
+        assert g.timing()["evaluations"] == 2
+        # and back to the default composition
+        g.set_params(E, synth.DEFAULT_BIAS, synth.DEFAULT_SN2, gpak.DIST_DIRECT)
+        Kd = orc.gram(X, X, E, synth.DEFAULT_BIAS, orc.DIST_DIRECT)
+        idf, _, _ = orc.nlz_lean(Kd, y, synth.DEFAULT_SN2)
+        assert abs(g.logLikelihood() - idf.nlz) <= 1e-9 * abs(idf.nlz)
     finally:
         g.close()
 
