@@ -62,8 +62,10 @@ int  gpak_create(gpak_ctx **out, int device, int precision);
  * surface -- `gp_ss_ak --gpus n` runs on it.  logLikelihood / alpha run on the block-column-cyclic schedule of
  * gpak_dist.h over all devices (RCCL panel broadcasts; an in-process peer-copy transport when RCCL cannot start or
  * several ranks share a device); the gradient is distributed by row blocks of B^-1 (gpak_dist_grad); prediction is
- * sharded over the test points with the factor replicated per device; Gram copies and solve_chol run on a replica of
- * the model on devices[0].  3-D inputs, ExpAns(+Bias). */
+ * sharded over the test points on the SAME distributed factor (each device assembles it from the packed panels its rank
+ * holds: nothing is factored again); solve_chol and the factor copy use it on devices[0]; Gram copies rebuild K there.
+ * 3- or 4-column inputs; any composition of gpak_set_kernel (for other children than ExpAns(+Bias) the gradients of
+ * gpak_grad_hyb are formed on devices[0] from the distributed factor). */
 int  gpak_create_multi(gpak_ctx **out, int n_gpus, const int *devices, int precision);
 int  gpak_n_gpus(const gpak_ctx *ctx);
 /* how the ranks of a multi-GPU context exchange panels: "rccl", "in-process peer copies" (+ the reason RCCL was
