@@ -492,7 +492,7 @@ def launch_multi(args, argv):
     N = args.gpus
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    limit = float(os.environ.get("GPAK_BENCH_CHILD_TIMEOUT_S", "420"))
+    limit = float(os.environ.get("GPAK_BENCH_CHILD_TIMEOUT_S", "300"))
     attempts = []
     order = [m for m in os.environ.get("GPAK_BENCH_MULTI_ORDER", "torchrun,inproc").split(",") if m]
     t_all = time.perf_counter()

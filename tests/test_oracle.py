@@ -261,6 +261,42 @@ def test_reference_style_gradient_against_numpy(orc):
     assert np.abs(g[[1, 3, 5, 6, 8, 9]] - gn[[1, 3, 5, 6, 8, 9]]).max() <= 1e-9 * scale
 
 
+@pytest.mark.parametrize("N,d", [(300, 3), (900, 3), (500, 4)])
+def test_streamed_gradient_equals_the_full_restatement(orc, N, d):
+    """orc_grad_ref_q (Q = B^-1 supplied by the caller, K / DD2 / QW / R rebuilt slab by slab -- what
+    tests/golden/make_golden_grad.py uses at N = 32768, where the six N x N arrays of orc_grad_ref_d do not fit) against
+    orc_grad_ref_d itself, with Q from NumPy's inverse: same sums, different association."""
+    X, y = (synth.drillholes4(N) if d == 4 else synth.drillholes(N))
+    K = orc.gram(X, X, E, BIAS, orc.DIST_DIRECT)
+    info, alpha, L = orc.nlz_lean(K, y, SN2)
+    g = orc.grad_ref(X, y, K, L, alpha, E, BIAS, SN2, orc.DIST_DIRECT)
+    Q = np.asfortranarray(np.linalg.inv(np.eye(N) + K / SN2))
+    gq = orc.grad_ref_q(X, y, Q, alpha, E, BIAS, SN2, orc.DIST_DIRECT)
+    assert np.abs(g - gq).max() <= 1e-11 * np.abs(g).max()
+    assert (gq[7] != 0.0) == (d == 4)
+    # a strided view (leading dimension > N) is accepted too
+    Qbig = np.zeros((N + 8, N), order="F")
+    Qbig[:N] = Q
+    assert np.abs(orc.grad_ref_q(X, y, Qbig[:N], alpha, E, BIAS, SN2, orc.DIST_DIRECT) - gq).max() <= 1e-13 * np.abs(g).max()
+
+
+def test_round3_goldens_are_consistent_with_the_earlier_ones():
+    """The gradient goldens were generated from their own factorisation: alpha must be the alpha of the nlZ goldens; the
+    L-BFGS fixture starts from the default parameters and never increases its kept objective."""
+    import json
+    for N in (8192, 32768):
+        a = json.load(open(os.path.join(GOLD, f"golden_N{N}.json")))["direct"]
+        g = json.load(open(os.path.join(GOLD, f"golden_grad_N{N}.json")))
+        assert abs(a["alpha_norm"] - g["alpha_norm"]) <= 1e-10 * a["alpha_norm"]
+        assert g["expans"] == [float(v) for v in E] and g["bias"] == BIAS and g["sn2"] == SN2 and len(g["g"]) == 10
+        assert g["g"][7] == 0.0 and g["q_symmetry_defect"] <= 1e-12
+    z = json.load(open(os.path.join(GOLD, "golden_lbfgs_N8192.json")))
+    obj = [r["objective"] for r in z["rows"]]
+    assert z["x0"] == [float(v) for v in E] + [BIAS, SN2] and all(b <= a for a, b in zip(obj, obj[1:]))
+    assert [r["evaluations"] for r in z["rows"]] == sorted(r["evaluations"] for r in z["rows"])
+    assert z["first_stall_iteration"] == 2 and len(z["rows"]) == z["maxit"] == 6
+
+
 def test_four_column_inputs_gram_gradient_prediction(orc):
     """a 4th (rock-type) input column with its own inverse width."""
     N = 70
