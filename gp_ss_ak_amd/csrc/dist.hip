@@ -252,7 +252,7 @@ struct gpak_dist {
   double *ld_slots = nullptr;
   int *info = nullptr;
   // gradient workspaces (allocated on the first gpak_dist_grad)
-  std::vector<double *> slabs;        // per rank: its rows of L^-T (rows_q x Np)
+  std::vector<double *> slabs;        // [0] own rows of L^-T (rows_a x Np), [1..2] receive buffers (gpak_dist_grad)
   double *binv = nullptr, *gpart = nullptr, *gred = nullptr;
   double grad_ms = 0;
   std::vector<double *> inv_own;      // per owned block: W/128 x 2 x 128 x 128
@@ -954,10 +954,11 @@ int gpak_dist_grad(gpak_dist *h, double *g) {
   auto tiles_of = [&](int q) { return Tn > q ? (Tn - q + P - 1) / P : 0; };
   const int Tmax = tiles_of(0), Ta = tiles_of(h->rank);
   if (h->slabs.empty()) {
-    h->slabs.assign(P, nullptr);
+    // [0] this rank's rows of L^-T, [1] and [2] the two buffers the other ranks' rows pass through
+    h->slabs.assign(P > 1 ? 3 : 1, nullptr);
     bool ok = true;
-    for (int q = 0; q < P && ok; q++) {
-      h->slabs[q] = (double *)E.alloc(E.self, sizeof(double) * std::max<size_t>(1, (size_t)tiles_of(q) * GPAK_TILE * Np));
+    for (size_t q = 0; q < h->slabs.size() && ok; q++) {
+      h->slabs[q] = (double *)E.alloc(E.self, sizeof(double) * std::max<size_t>(1, (size_t)(q ? Tmax : Ta) * GPAK_TILE * Np));
       ok = h->slabs[q] != nullptr;
     }
     h->binv = (double *)E.alloc(E.self, sizeof(double) * std::max<size_t>(1, (size_t)Ta * GPAK_TILE * P * Tmax * GPAK_TILE));
@@ -967,12 +968,30 @@ int gpak_dist_grad(gpak_dist *h, double *g) {
   }
   h->sync_used = 0; h->time_used = 0;
   const size_t t0 = h->time_event(h->s_bulk);
-  DCHK(E.grad_g_rows(h->s_bulk, Np, h->nb, P, h->rank, h->panels.data(), h->invs.data(), h->slabs[h->rank]));
-  DCHK(hop_in(h));
-  for (int q = 0; q < P; q++)
-    if (tiles_of(q) > 0) DCHK(T.bcast(T.self, h->s_comm, h->slabs[q], (size_t)tiles_of(q) * GPAK_TILE * Np, q));
-  DCHK(hop_out(h));
-  DCHK(E.grad_binv_rows(h->s_bulk, Np, P, h->rank, h->slabs.data(), h->binv));
+  double *own = h->slabs[0];
+  DCHK(E.grad_g_rows(h->s_bulk, Np, h->nb, P, h->rank, h->panels.data(), h->invs.data(), own));
+  // The slabs go round one at a time: rank q's is broadcast into one of two receive buffers while the product against
+  // the previous one runs out of the other, so a rank never holds more than its own slab and two in flight.
+  void *e_read[2] = {nullptr, nullptr};   // recorded behind the product that last read the receive buffer
+  int slot = 0;
+  for (int q = 0; q < P; q++) {
+    if (tiles_of(q) == 0) continue;
+    double *buf = own;
+    if (q == h->rank) {
+      DCHK(hop_in(h));                     // the slab is this rank's to send once grad_g_rows has written it
+    } else {
+      buf = h->slabs[1 + slot];
+      if (e_read[slot] && h->s_comm != h->s_bulk) DCHK(E.stream_wait_event(E.self, h->s_comm, e_read[slot]));
+    }
+    DCHK(T.bcast(T.self, h->s_comm, buf, (size_t)tiles_of(q) * GPAK_TILE * Np, q));
+    DCHK(hop_out(h));
+    DCHK(E.grad_binv_rows(h->s_bulk, Np, P, h->rank, q, own, buf, h->binv));
+    if (q != h->rank) {
+      e_read[slot] = h->sync_event();
+      DCHK(E.event_record(E.self, e_read[slot], h->s_bulk));
+      slot ^= 1;
+    }
+  }
   DCHK(E.grad_pairs_rows(h->s_bulk, h->u, h->cap, h->x_soa, Np, h->N, Np, h->y, h->f, h->alpha, h->binv, P, h->rank,
                          h->expans, h->bias, h->sn2, h->kmode(), h->gpart, h->gred));
   DCHK(hop_in(h));

@@ -461,20 +461,19 @@ extern "C" int gpak_dev_grad_g_rows(void *stream, int Np, int nb, int P, int a, 
 }
 
 // binv: rows_a x (P * Tmax * 128), leading dimension rows_a; the 128-column group of global block g = u*P + b sits at
-// group index b*Tmax + u (so that one launch per source slab writes a contiguous range of tile columns)
-extern "C" int gpak_dev_grad_binv_rows(void *stream, int Np, int P, int a, const double *const *slabs, double *binv) {
+// group index b*Tmax + u (so that the launch for source rank b writes a contiguous range of tile columns).  One call
+// per source rank: the caller needs only its own slab and the one that is passing through (dist.hip streams them)
+extern "C" int gpak_dev_grad_binv_rows(void *stream, int Np, int P, int a, int b, const double *slab_a, const double *slab_b,
+                                       double *binv) {
   hipStream_t st = (hipStream_t)stream;
-  const int Ta = my_tiles(Np, P, a), Tmax = my_tiles(Np, P, 0);
-  if (Ta == 0) return GPAK_OK;
+  if (b < 0 || b >= P || a < 0 || a >= P) return GPAK_EINVAL;
+  const int Ta = my_tiles(Np, P, a), Tb = my_tiles(Np, P, b), Tmax = my_tiles(Np, P, 0);
+  if (Ta == 0 || Tb == 0) return GPAK_OK;
   const long rows = (long)Ta * PB;
-  for (int b = 0; b < P; b++) {
-    const int Tb = my_tiles(Np, P, b);
-    if (Tb == 0) continue;
-    // tile (t, u): global row block t*P + a, global column block u*P + b; needed when u*P + b <= t*P + a, i.e.
-    // skipped when t < u + (b > a ? 1 : 0)
-    gpak_launch_gemm_nt_k0map(st, Ta, Tb, Np, 1.0, slabs[a], rows, slabs[b], (long)Tb * PB,
-                              binv + (size_t)b * Tmax * PB * rows, rows, b > a ? 1 : 0, P, a);
-  }
+  // tile (t, u): global row block t*P + a, global column block u*P + b; needed when u*P + b <= t*P + a, i.e.
+  // skipped when t < u + (b > a ? 1 : 0)
+  gpak_launch_gemm_nt_k0map(st, Ta, Tb, Np, 1.0, slab_a, rows, slab_b, (long)Tb * PB, binv + (size_t)b * Tmax * PB * rows,
+                            rows, b > a ? 1 : 0, P, a);
   return hipGetLastError() == hipSuccess ? GPAK_OK : GPAK_EHIP;
 }
 

@@ -56,7 +56,7 @@ ENGINE_FIELDS = [
     ("vec_scale", _F(C.c_int, _vp, C.c_int, _vp, C.c_double, _vp)),
     ("vec_sum", _F(C.c_int, _vp, C.c_int, _vp, _vp)),
     ("grad_g_rows", _F(C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp), _vp)),
-    ("grad_binv_rows", _F(C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), _vp)),
+    ("grad_binv_rows", _F(C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp)),
     ("grad_pairs_rows", _F(C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                            _dp, C.c_double, C.c_double, C.c_int, _vp, _vp)),
     # the row-block x column-block layout (gpak_grid_*)

@@ -105,17 +105,20 @@ int gpak_dev_pack(void *stream, const double *src, long ld, int row0, int nrows,
 
 /* ---- the reference-style gradient (GP_utils::GradLL, GP_Utils.cpp:1171-1262) distributed over P ranks that all hold
  * the factor as packed panels.  128-row block g of G = L^-T and of B^-1 belongs to rank g % P.
- * panels / invs / slabs are HOST arrays of device pointers (one per block column / per rank).
+ * panels / invs are HOST arrays of device pointers (one per block column).
  * gpak_dev_grad_g_rows: slab (rows_a x Np doubles, leading dimension rows_a = 128 * number of owned row blocks) <- the
  *   owned rows of L^-T by blocked forward substitution on identity rows (N^3/(3P) flops).
- * gpak_dev_grad_binv_rows: binv (rows_a x P*Tmax*128, Tmax = ceil(Np/128 / P)) <- the owned rows of B^-1 = G G^T,
- *   lower part; the 128-column group of global block g sits at group index (g % P) * Tmax + g / P.
+ * gpak_dev_grad_binv_rows: binv (rows_a x P*Tmax*128, Tmax = ceil(Np/128 / P)) <- the column groups of source rank b
+ *   of the owned rows of B^-1 = G G^T (lower part), from this rank's slab and rank b's (the same pointer when b == a);
+ *   the 128-column group of global block g sits at group index (g % P) * Tmax + g / P.  One call per source rank, so a
+ *   caller holds its own slab and the one passing through, never all P.
  * gpak_dev_grad_pairs_rows: out[0..16) <- this rank's share of the pair sums (to be all-reduced), out[16] <- the
  *   replicated lp_dhyp sum; part = scratch of rows_a/128 * Np/64 * 16 doubles.
  * gpak_dev_grad_finish (host only): g[10] = {8 ExpAns, bias, sn2} from the all-reduced sums. */
 int gpak_dev_grad_g_rows(void *stream, int Np, int nb, int P, int a, const double *const *panels,
                          const double *const *invs, double *slab);
-int gpak_dev_grad_binv_rows(void *stream, int Np, int P, int a, const double *const *slabs, double *binv);
+int gpak_dev_grad_binv_rows(void *stream, int Np, int P, int a, int b, const double *slab_a, const double *slab_b,
+                            double *binv);
 int gpak_dev_grad_pairs_rows(void *stream, const double *u, int cap, const double *x_soa, int xs, int n, int Np,
                              const double *y, const double *f, const double *alpha, const double *binv, int P, int a,
                              const double *expans, double bias, double sn2, int dist_mode, double *part, double *out);

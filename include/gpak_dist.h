@@ -82,7 +82,7 @@ typedef struct gpak_dist_engine {
   /* the distributed gradient (gpak_dev.h) */
   int (*grad_g_rows)(void *stream, int Np, int nb, int P, int a, const double *const *panels, const double *const *invs,
                      double *slab);
-  int (*grad_binv_rows)(void *stream, int Np, int P, int a, const double *const *slabs, double *binv);
+  int (*grad_binv_rows)(void *stream, int Np, int P, int a, int b, const double *slab_a, const double *slab_b, double *binv);
   int (*grad_pairs_rows)(void *stream, const double *u, int cap, const double *x_soa, int xs, int n, int Np,
                          const double *y, const double *f, const double *alpha, const double *binv, int P, int a,
                          const double *expans, double bias, double sn2, int dist_mode, double *part, double *out);
@@ -163,8 +163,10 @@ int gpak_dist_nlz_terms(gpak_dist *h, double *quad, double *sumlp, double *logde
 /* GP_utils::GradLL (GP_Utils.cpp:1171-1262) with the children's getGradients as written (Kernel.cpp:886-1263, 370-377),
  * g[10] = {8 ExpAns, bias, sn2}, same value on every rank.  Distributed by 128-row blocks of L^-T and B^-1 (block g on
  * rank g % P): each rank forms its rows of L^-T from the packed panels it already holds (N^3/(3P) flops, no
- * communication), the row slabs are all-gathered (P broadcasts, N^2 doubles in total), each rank forms its rows of
- * B^-1 = L^-T L^-1 (N^3/(3P)) and runs the fused pair pass on them; one 16-double all-reduce. */
+ * communication), the row slabs go round one at a time (P broadcasts, N^2 doubles in total, each received into one of
+ * two buffers while the product against the previous one runs), each rank forms its rows of B^-1 = L^-T L^-1
+ * (N^3/(3P)) and runs the fused pair pass on them; one 16-double all-reduce.  Per-rank workspace: its own slab, two
+ * receive buffers and its rows of B^-1, 4 N^2/P doubles in all. */
 int gpak_dist_grad(gpak_dist *h, double *g);
 /* failing column (1-based, the same on every rank) of the last GPAK_ENOTPD, 0 if none: GP_utils::Chol_fail */
 int gpak_dist_failed_column(const gpak_dist *h);

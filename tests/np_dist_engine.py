@@ -170,21 +170,17 @@ class NumpyDistEngine:
             if len(rows):
                 _strided(slab, len(rows), Np, len(rows))[:] = G[rows, :]
 
-        def grad_binv_rows(st, Np, P, a, slabs, binv):
-            G = np.zeros((Np, Np))
-            for q in range(P):
-                rq = my_rows(Np, P, q)
-                if len(rq):
-                    G[rq, :] = _strided(slabs[q], len(rq), Np, len(rq))
-            rows, Tmax = my_rows(Np, P, a), my_tiles(Np, P, 0)
-            if not len(rows):
+        def grad_binv_rows(st, Np, P, a, b, slab_a, slab_b, binv):
+            rows, rb, Tmax = my_rows(Np, P, a), my_rows(Np, P, b), my_tiles(Np, P, 0)
+            if not len(rows) or not len(rb):
                 return
-            Bi = G[rows, :] @ G.T                                    # my rows of B^-1 = G G^T
+            Ga = _strided(slab_a, len(rows), Np, len(rows))
+            Gb = _strided(slab_b, len(rb), Np, len(rb))
+            Bi = Ga @ Gb.T                                           # my rows of B^-1 = G G^T, columns of rank b
             out = _strided(binv, len(rows), P * Tmax * TILE, len(rows))
-            out[:] = 0.0
-            for g in range(Np // TILE):
-                c0 = ((g % P) * Tmax + g // P) * TILE
-                out[:, c0:c0 + TILE] = Bi[:, g * TILE:(g + 1) * TILE]
+            for u in range(len(rb) // TILE):
+                c0 = (b * Tmax + u) * TILE
+                out[:, c0:c0 + TILE] = Bi[:, u * TILE:(u + 1) * TILE]
 
         def grad_pairs_rows(st, u, cap, x_soa, xs, n, Np, y, f, alpha, binv, P, a, expans, bias, sn2, mode, part, out):
             lib = gd._load()
