@@ -254,3 +254,35 @@ def test_config4_n65536_sharded_over_four_ranks(gp):
         assert abs(q - z["quad"]) <= 1e-9 * abs(z["quad"]) and abs(s - z["sumlp"]) <= 1e-9 * abs(z["sumlp"])
         assert rel(a[idx], z["alpha_samples"]) <= 1e-8
     gp.set_train(X[:64], y[:64])
+
+
+@pytest.mark.parametrize("N", [98304, 131072])
+def test_largest_single_gpu_sizes_by_residual(orc, N):
+    """The 288 GB device holds the fp64 factor of N = 131072 (137 GB): beyond every golden, so the check is the
+    size-independent one -- (K + sn2 I) alpha = y on 96 random rows, K rebuilt by the oracle on the host -- plus the
+    quadratic term the library reports against alpha^T (y - sn2 alpha) / 2.  Catches 32-bit index arithmetic
+    (N^2 = 2^34 elements) in every kernel on the path."""
+    X, y = synth.drillholes(N)
+    g = gpak.Gpak(0)
+    try:
+        g.set_train(X, y)
+        g.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        nlz = g.logLikelihood()
+        t = g.timing()
+        q, slp, ld = g.nlz_terms()
+        alpha = g.solve_alpha()
+    finally:
+        g.close()
+    rng = np.random.default_rng(N)
+    idx = np.sort(rng.choice(N, 96, replace=False))
+    idx[0], idx[-1] = 0, N - 1
+    Krows = orc.gram(np.asfortranarray(X[idx]), X, E, BIAS, gpak.DIST_DIRECT)
+    r = Krows @ alpha + SN2 * alpha[idx] - y[idx]
+    res = np.abs(r).max() / np.abs(y).max()
+    flops = N ** 3 / 3.0
+    print(f"\nN={N}: factor {t['factor_ms']:.0f} ms = {flops / t['factor_ms'] / 1e9:.1f} TFLOP/s, nlz {nlz:.6f}, "
+          f"row residual {res:.2e}, |alpha| {np.linalg.norm(alpha):.6e}")
+    assert math.isfinite(nlz) and math.isfinite(ld) and np.isfinite(alpha).all()
+    assert res <= 1e-9
+    # quad = alpha^T (K alpha) / 2 (GP_Utils.cpp:1147-1160) and K alpha = y - sn2 alpha
+    assert abs(0.5 * float(alpha @ (y - SN2 * alpha)) - q) <= 1e-9 * abs(q)
