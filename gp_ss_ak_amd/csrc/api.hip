@@ -51,6 +51,7 @@ static GpakTuning read_tuning_env() {
   geti("GPAK_TAIL_ROWS", t.tail_rows);
   getb("GPAK_SUB_NEXT", t.sub_next);
   getb("GPAK_INV512", t.inv512);
+  geti("GPAK_BWD_FUSED", t.bwd_fused);
   geti("GPAK_BWD_BLOCK", t.bwd_block);
   getb("GPAK_LOOKAHEAD", t.lookahead);
   getb("GPAK_FWD_IN_FACTOR", t.fwd_in_factor);
@@ -183,11 +184,12 @@ static void release_train(gpak_ctx *ctx) {
   if (ctx->dM) hipFree(ctx->dM);
   if (ctx->dInv) hipFree(ctx->dInv);
   if (ctx->dInv512) hipFree(ctx->dInv512);
+  if (ctx->dT512) hipFree(ctx->dT512);
   if (ctx->dAlpha) hipFree(ctx->dAlpha);
   if (ctx->dWork) hipFree(ctx->dWork);
   if (ctx->dF) hipFree(ctx->dF);
   gpak_grad_release(ctx);
-  ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dInv512 = ctx->dAlpha = ctx->dWork = ctx->dF = nullptr;
+  ctx->dX = ctx->dy = ctx->dM = ctx->dInv = ctx->dInv512 = ctx->dT512 = ctx->dAlpha = ctx->dWork = ctx->dF = nullptr;
   free_points(ctx->U);
   if (ctx->dLf) hipFree(ctx->dLf);
   if (ctx->dInvf) hipFree(ctx->dInvf);
@@ -351,6 +353,10 @@ int gpak_set_option(gpak_ctx *ctx, int option, long value) {
       ctx->tune.potrf_co = (int)value;
       return GPAK_OK;
     case GPAK_OPT_PRED_BATCH: ctx->tune.pred_batch = (int)value; return GPAK_OK;
+    case GPAK_OPT_BWD_FUSED:
+      if (value < 0 || value > 2) { ctx->err = "bwd_fused must be 0, 1 or 2"; return GPAK_EINVAL; }
+      ctx->tune.bwd_fused = (int)value;
+      return GPAK_OK;
   }
   ctx->err = "unknown option";
   return GPAK_EINVAL;
@@ -385,10 +391,12 @@ int gpak_set_train(gpak_ctx *ctx, const double *X, const double *y, int N, int d
       hipMalloc(&ctx->dM, sizeof(double) * (size_t)ld * Np) != hipSuccess ||
       hipMalloc(&ctx->dInv, sizeof(double) * (size_t)T * 2 * GPAK_TILE * GPAK_TILE) != hipSuccess ||
       hipMalloc(&ctx->dInv512, sizeof(double) * (size_t)((Np + bw - 1) / bw) * bw * bw) != hipSuccess ||
+      hipMalloc(&ctx->dT512, sizeof(double) * (size_t)(2 * ((Np + bw - 1) / bw)) * bw * bw) != hipSuccess ||
       hipMalloc(&ctx->dAlpha, sizeof(double) * (size_t)Np) != hipSuccess ||
       hipMalloc(&ctx->dF, sizeof(double) * (size_t)Np) != hipSuccess ||
-      // 70 Np doubles of vectors + the back substitution's scratch for the widest block ((8 + bw / 32) * bw, solve.hip)
-      hipMalloc(&ctx->dWork, sizeof(double) * (70 * (size_t)Np + (size_t)(8 + bw / 32) * bw)) != hipSuccess) {
+      // 70 Np doubles of vectors + the back substitution's scratch for the widest block ((8 + bw / 32) * bw for the
+      // three-launch step, 34 * bw for the fused one: solve.hip)
+      hipMalloc(&ctx->dWork, sizeof(double) * (70 * (size_t)Np + (size_t)std::max(8 + bw / 32, 34) * bw)) != hipSuccess) {
     ctx->err = "device allocation failed for the training set";
     release_train(ctx);
     return GPAK_ENOMEM;
@@ -497,6 +505,7 @@ static int ensure_factor(gpak_ctx *ctx) {
   ctx->mstate = gpak_ctx::M_B;
   ctx->z_ok = false;
   ctx->inv512_ok = false;
+  ctx->t512_mode = 0;
   ctx->lf_ok = false;
   if (ctx->fwd_in_factor) gpak_launch_scale(st, ctx->Np, ctx->dy, 1.0 / ctx->sn2, ctx->dWork);  // rhs = y/sn2
   GPAK_HIP(hipEventRecord(ctx->ev[1], st));
@@ -520,7 +529,8 @@ static int ensure_factor(gpak_ctx *ctx) {
   if (rc) return rc;
   ctx->mstate = gpak_ctx::M_L;
   ctx->z_ok = ctx->fwd_in_factor;
-  ctx->inv512_ok = ctx->fwd_in_factor && ctx->tune.inv512;
+  ctx->t512_mode = ctx->fwd_in_factor && ctx->tune.inv512 ? ctx->tune.bwd_fused : 0;
+  ctx->inv512_ok = ctx->fwd_in_factor && ctx->tune.inv512 && ctx->t512_mode != 2;   // mode 2 builds [R ; T] elsewhere
   return GPAK_OK;
 }
 
@@ -537,8 +547,14 @@ static int ensure_alpha(gpak_ctx *ctx) {
     gpak_launch_trsv_fwd(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
   }
   ctx->z_ok = false;  // the back substitution consumes w1
-  gpak_launch_trsv_bwd2(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha, ctx->dWork + 2 * (size_t)ctx->Np,
-                        ctx->inv512_ok ? ctx->dInv512 : nullptr, ctx->bwd_bw);
+  if (ctx->t512_mode)
+    gpak_launch_trsv_bwd3(st, ctx->Np, ctx->dM, ctx->ld, w1, ctx->dAlpha, ctx->dWork + 2 * (size_t)ctx->Np,
+                          ctx->t512_mode == 2 ? ctx->dT512 : ctx->dInv512,
+                          (size_t)(ctx->t512_mode == 2 ? 2 : 1) * ctx->bwd_bw * ctx->bwd_bw,
+                          (ctx->t512_mode == 2 ? 2 : 1) * ctx->bwd_bw, ctx->t512_mode == 2, ctx->bwd_bw);
+  else
+    gpak_launch_trsv_bwd2(st, ctx->Np, ctx->dM, ctx->ld, ctx->dInv, w1, ctx->dAlpha, ctx->dWork + 2 * (size_t)ctx->Np,
+                          ctx->inv512_ok ? ctx->dInv512 : nullptr, ctx->bwd_bw);
   GPAK_HIP(hipEventRecord(ctx->ev[4], st));
   GPAK_HIP(hipEventSynchronize(ctx->ev[4]));
   float ms = 0;
@@ -606,6 +622,7 @@ int gpak_import_factor(gpak_ctx *ctx, const gpak_dist_factor_view *v) {
   ctx->mstate = gpak_ctx::M_L;
   ctx->z_ok = false;         // dWork does not hold L^-1 (y/sn2)
   ctx->inv512_ok = false;    // the 512-block inverses were not imported: back substitutions use the 128-blocks
+  ctx->t512_mode = 0;
   ctx->lf_ok = false;        // the fp32 image (GPAK_F32 prediction) is rebuilt from this factor on first use
   ctx->alpha_ok = true; ctx->nlz_ok = true;
   ctx->failed_col = 0;

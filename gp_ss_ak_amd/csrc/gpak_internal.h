@@ -61,6 +61,8 @@ struct GpakTuning {
   int tail_rows = 12288;       // GPAK_TAIL_ROWS     rows left from which the bulk updates use the CU-masked queue
   bool sub_next = false;       // GPAK_SUB_NEXT      tail: next block column updated sub-panel by sub-panel
   bool inv512 = true;          // GPAK_INV512        explicit diagonal-block inverses for the back substitution
+  int bwd_fused = 2;           // GPAK_BWD_FUSED     back substitution: 0 three launches per step, 1 far column dots under the diagonal
+                               //                    step (two launches), 2 one launch (coupling blocks T_b): solve.hip
   int bwd_block = 512;         // GPAK_BWD_BLOCK     ... of this width: 512, 1024 or 2048 columns per back-substitution step
                                //                    (measured round 3: solve 1.72 / 1.42 / 1.33 ms at N = 32768, but the wider inverses cost
                                //                    the factorisation as much or more: profiles/r03_bwd_block.txt)
@@ -127,7 +129,9 @@ struct gpak_ctx {
   double *dInv = nullptr;    // (Np/128) inverted 128x128 diagonal blocks of L
   double *dInv512 = nullptr; // explicit (L_bb^-1)^T of the bw x bw diagonal blocks (bw = bwd_bw; back substitution)
   int bwd_bw = 512;          // block width dInv512 was sized and is being built for
+  double *dT512 = nullptr;   // bwd_fused = 2: per block column the stacked [R_b ; T_b], T_b = L[b, b-1]^T R_b (2 bw x bw: solve.hip)
   bool inv512_ok = false;
+  int t512_mode = 0;         // fused back substitution of the current factor: 0 no, 1 from dInv512, 2 from dT512
   double *dAlpha = nullptr;  // Np
   double *dWork = nullptr;   // 4*Np scratch vectors
   double *dRed = nullptr;    // small reduction scratch
@@ -336,9 +340,13 @@ void gpak_launch_trsv_bwd_block2(hipStream_t st, int Np, int J, int W, const dou
                                  const double *z, double *out, double *scratch, const double *Rinv = nullptr, int NB = 512);
 // R = (L_bb^-1)^T of the W x W diagonal block at J (W <= 512), column-major ld 512; seven small GEMM launches
 void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R,
-                              int RL = 512);
+                              int RL = 512, int extra = 0);
 void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, const double *inv, const double *z,
                            double *out, double *scratch, const double *RinvB = nullptr, int bw = 512);
+// far column dots of the next block column under the diagonal step of this one (solve.hip): scratch 18 * NB doubles,
+// OP = per block column R_b (and, with_T, T_b in the rows below it: gpak_launch_diag_inverse with extra = NB)
+void gpak_launch_trsv_bwd3(hipStream_t st, int Np, const double *L, long ld, const double *z, double *out, double *scratch,
+                           const double *OP, size_t op_stride, int RL, bool with_T, int NB);
 void gpak_launch_trsv_bwd(hipStream_t st, int Np, const double *L, long ld, const double *inv, double *x,
                           double *out);
 void gpak_launch_trsv_fwd_block(hipStream_t st, int Np, int J, int W, const double *L, long ld,

@@ -662,8 +662,13 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
       const int bw = ctx->bwd_bw;
       while (inv512 && done512 * bw < Np && (std::min(Np, (done512 + 1) * bw) <= J + W)) {
         const int j5 = done512 * bw;
-        gpak_launch_diag_inverse(sf, j5, std::min(bw, Np - j5), ctx->dM, ctx->ld, ctx->dInv,
-                                 ctx->dInv512 + (size_t)done512 * bw * bw, bw);
+        const int w5 = std::min(bw, Np - j5);
+        // bwd_fused = 2: with the block that couples it to the block column on its left riding along (solve.hip)
+        if (ctx->tune.bwd_fused == 2)
+          gpak_launch_diag_inverse(sf, j5, w5, ctx->dM, ctx->ld, ctx->dInv, ctx->dT512 + (size_t)done512 * 2 * bw * bw, 2 * bw,
+                                   j5 > 0 ? bw : 0);
+        else
+          gpak_launch_diag_inverse(sf, j5, w5, ctx->dM, ctx->ld, ctx->dInv, ctx->dInv512 + (size_t)done512 * bw * bw, bw);
         done512++;
       }
     }

@@ -261,8 +261,14 @@ int gpak_solve_chol_impl(gpak_ctx *ctx, double *X_host, int k) {
     GPAK_HIP(hipMemsetAsync(w0, 0, sizeof(double) * Np, st));
     GPAK_HIP(hipMemcpyAsync(w0, X_host + (size_t)c * N, sizeof(double) * N, hipMemcpyHostToDevice, st));
     gpak_launch_trsv_fwd(st, Np, ctx->dM, ctx->ld, ctx->dInv, w0, w1);
-    gpak_launch_trsv_bwd2(st, Np, ctx->dM, ctx->ld, ctx->dInv, w1, w2, ctx->dWork + 3 * (size_t)Np,
-                          ctx->inv512_ok ? ctx->dInv512 : nullptr, ctx->bwd_bw);
+    if (ctx->t512_mode)
+      gpak_launch_trsv_bwd3(st, Np, ctx->dM, ctx->ld, w1, w2, ctx->dWork + 3 * (size_t)Np,
+                            ctx->t512_mode == 2 ? ctx->dT512 : ctx->dInv512,
+                            (size_t)(ctx->t512_mode == 2 ? 2 : 1) * ctx->bwd_bw * ctx->bwd_bw,
+                            (ctx->t512_mode == 2 ? 2 : 1) * ctx->bwd_bw, ctx->t512_mode == 2, ctx->bwd_bw);
+    else
+      gpak_launch_trsv_bwd2(st, Np, ctx->dM, ctx->ld, ctx->dInv, w1, w2, ctx->dWork + 3 * (size_t)Np,
+                            ctx->inv512_ok ? ctx->dInv512 : nullptr, ctx->bwd_bw);
     GPAK_HIP(hipMemcpyAsync(X_host + (size_t)c * N, w2, sizeof(double) * N, hipMemcpyDeviceToHost, st));
   }
   GPAK_HIP(hipStreamSynchronize(st));

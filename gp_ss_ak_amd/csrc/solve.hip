@@ -217,11 +217,28 @@ __global__ void gpak_identity_w_f64(double *R, int ld, int W) {
   const int c = i / ld, r = i - c * ld;
   R[i] = (r == c) ? 1.0 : 0.0;
 }
+__global__ __launch_bounds__(256) void gpak_transpose_f64(int rows, int cols, const double *__restrict__ src, long lds,
+                                                           double *__restrict__ dst, long ldd) {
+  __shared__ double tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8)
+    if (r0 + tx < rows && c0 + k < cols) tile[k][tx] = src[(r0 + tx) + (size_t)(c0 + k) * lds];
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + tx < cols && r0 + k < rows) dst[(c0 + tx) + (size_t)(r0 + k) * ldd] = tile[tx][k];
+}
+
+// `extra` more right-hand-side rows ride along below the identity (RL >= W + extra): the rows of
+// L[J..J+W, J-extra..J)^T, which the same substitution turns into T = L[b, b-1]^T L_bb^-T, the coupling block of the
+// one-launch back-substitution step -- no launch of its own, and the seven products are latency-bound at either height
 void gpak_launch_diag_inverse(hipStream_t st, int J, int W, const double *L, long ld, const double *inv, double *R,
-                              int RL) {
+                              int RL, int extra) {
   // RL: leading dimension of R = the block width of the caller's back substitution (512 unless told otherwise)
   hipLaunchKernelGGL(gpak_identity_w_f64, dim3((W * RL + 255) / 256), dim3(256), 0, st, R, RL, W);
-  const int mt = W / SB;
+  if (extra > 0)
+    hipLaunchKernelGGL(gpak_transpose_f64, dim3((W + 31) / 32, (extra + 31) / 32), dim3(256), 0, st, W, extra,
+                       L + J + (size_t)(J - extra) * ld, ld, R + W, (long)RL);
+  const int mt = (W + extra) / SB;
   for (int j0 = 0; j0 < W; j0 += SB) {
     const double *ib = inv + (size_t)((J + j0) / SB) * 2 * SB * SB;
     double *Rj = R + (size_t)j0 * RL;
@@ -291,6 +308,159 @@ void gpak_launch_trsv_bwd2(hipStream_t st, int Np, const double *L, long ld, con
     const int J = b * NB, W = min(NB, Np - J);
     gpak_launch_trsv_bwd_block2(st, Np, J, W, L, ld, inv, z, out, scratch, RinvB ? RinvB + (size_t)b * NB * NB : nullptr,
                                 NB);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Back substitution with the column dots of the NEXT block column under the diagonal step of this one (round 3).
+// The column dots of block b-1 split into the rows of block b ("near": they need out_b, the newest piece of the
+// solution) and everything below ("far": known one step earlier, and nearly all of the bytes).  Step b:
+//   launch A(b)   workgroups [0, nmv): 16 rows each of R_b times v_b, v_b = z_b - far_b - near_b     -> out_b
+//                 the others:          far_{b-1}[c] = sum_{i >= J_b + W_b} L[i, c] out[i]   (rows split as in
+//                                      gpak_coldot_split_f64) -- the HBM-bound part, nothing in it waits for out_b
+//   launch B(b)   near_{b-1}[c] = sum_{i in block b} L[i, c] out_b[i]                        (2 MB, bwd_fused = 1)
+// With the coupling block T_b = L[b, b-1]^T R_b (built beside the factorisation, bwd_fused = 2) near_{b-1} = T_b v_b is
+// a function of the same v_b, the rows of T_b join those of R_b in launch A, and B disappears: one launch per step,
+// every workgroup of which depends on EARLIER launches only.
+// The matrix-vector part reads R_b / T_b as they are built (column-major, rows along the lanes): a workgroup takes 16
+// rows, a lane one row and every fourth column of its wave's quarter, with all 32 loads of a 512-column block in flight
+// at once (64 rows per workgroup and four loads in flight: 28 us per step instead of 4).
+// far / near are double-buffered by the parity of b (a launch reads the set its predecessor wrote).
+// ---------------------------------------------------------------------------------------
+#define BS_MAXW 2048
+#define BS_ROWS 16   // operator rows per workgroup (4 per wave)
+#define BS_SPLITS 8  // most row splits of the far column dots
+template <int FU>
+__global__ __launch_bounds__(256) void gpak_bwd_step_f64(int Np, int J, int W, int Jp, int Wp, const double *__restrict__ R,
+                                                          const double *__restrict__ T, int RL, const double *__restrict__ z,
+                                                          const double *__restrict__ far_in, int nsplit_in,
+                                                          const double *__restrict__ near_in, int part_ld, double *out,
+                                                          double *__restrict__ near_out, double *__restrict__ far_out,
+                                                          int rows_per_split, int nsplit_out, int nmv,
+                                                          const double *__restrict__ L, long ld) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if ((int)blockIdx.x < nmv) {
+    __shared__ double v[BS_MAXW];
+    for (int c = t; c < W; c += 256) {
+      double p[BS_SPLITS];   // all loads issued before the first add (a loop over nsplit_in waits for each in turn)
+#pragma unroll
+      for (int r = 0; r < BS_SPLITS; r++) p[r] = r < nsplit_in ? far_in[(size_t)r * part_ld + c] : 0.0;
+      const double nr = near_in ? near_in[c] : 0.0, zc = z[J + c];
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < BS_SPLITS; r++) s += p[r];   // fixed order
+      v[c] = zc - (s + nr);
+    }
+    __syncthreads();
+    __shared__ double ps[4][BS_ROWS];
+    const int r0 = blockIdx.x * BS_ROWS, row = lane & 15, ph = lane >> 4;
+    const double *M = (r0 < W ? R + r0 : T + (r0 - W)) + row;   // 16 rows of the stacked [R_b ; T_b]
+    const int cq = W / 4, cb = w * cq + ph;                    // this wave's quarter of the columns, every fourth one
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // R_b is upper triangular: a quarter of the columns that lies left of these rows is all zeros
+    const int c_end = (r0 < W && (w + 1) * cq <= r0) ? 0 : cq;
+    for (int c0 = 0; c0 < c_end; c0 += 128) {
+      double m[32];
+#pragma unroll
+      for (int u = 0; u < 32; u++) m[u] = (c0 + 4 * u < cq) ? M[(size_t)(cb + c0 + 4 * u) * RL] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 32; u++)
+        if (c0 + 4 * u < cq) acc[u & 3] = fma(m[u], v[cb + c0 + 4 * u], acc[u & 3]);
+    }
+    double a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    a += __shfl_xor(a, 16);
+    a += __shfl_xor(a, 32);
+    if (lane < BS_ROWS) ps[w][lane] = a;
+    __syncthreads();
+    if (t < BS_ROWS) {
+      const double r = (ps[0][t] + ps[1][t]) + (ps[2][t] + ps[3][t]);
+      if (r0 < W) out[J + r0 + t] = r;
+      else near_out[r0 - W + t] = r;
+    }
+    return;
+  }
+  const int g = blockIdx.x - nmv, ngrp = Wp / 4;
+  const int c = Jp + (g % ngrp) * 4 + w, split = g / ngrp;
+  if (split >= nsplit_out) return;
+  const int rb = J + W + split * rows_per_split;
+  const int re = min(Np, rb + rows_per_split);
+  const double *Lc = L + (size_t)c * ld;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  int i = rb + 2 * lane;
+  if (FU == 4) {
+    double c0 = 0.0, c1 = 0.0, d0 = 0.0, d1 = 0.0;
+    for (; i + 384 < re; i += 512) {   // four independent 1-KiB pieces per trip
+      const double2 l0 = *reinterpret_cast<const double2 *>(Lc + i), l1 = *reinterpret_cast<const double2 *>(Lc + i + 128);
+      const double2 l2 = *reinterpret_cast<const double2 *>(Lc + i + 256), l3 = *reinterpret_cast<const double2 *>(Lc + i + 384);
+      const double2 v0 = *reinterpret_cast<const double2 *>(out + i), v1 = *reinterpret_cast<const double2 *>(out + i + 128);
+      const double2 v2 = *reinterpret_cast<const double2 *>(out + i + 256), v3 = *reinterpret_cast<const double2 *>(out + i + 384);
+      a0 = fma(l0.x, v0.x, a0); a1 = fma(l0.y, v0.y, a1);
+      b0 = fma(l1.x, v1.x, b0); b1 = fma(l1.y, v1.y, b1);
+      c0 = fma(l2.x, v2.x, c0); c1 = fma(l2.y, v2.y, c1);
+      d0 = fma(l3.x, v3.x, d0); d1 = fma(l3.y, v3.y, d1);
+    }
+    a0 += c0; a1 += c1; b0 += d0; b1 += d1;
+  }
+  for (; i + 128 < re; i += 256) {   // two independent 1-KiB pieces per trip
+    const double2 l0 = *reinterpret_cast<const double2 *>(Lc + i), v0 = *reinterpret_cast<const double2 *>(out + i);
+    const double2 l1 = *reinterpret_cast<const double2 *>(Lc + i + 128), v1 = *reinterpret_cast<const double2 *>(out + i + 128);
+    a0 = fma(l0.x, v0.x, a0); a1 = fma(l0.y, v0.y, a1);
+    b0 = fma(l1.x, v1.x, b0); b1 = fma(l1.y, v1.y, b1);
+  }
+  for (; i < re; i += 128) {
+    const double2 l0 = *reinterpret_cast<const double2 *>(Lc + i), v0 = *reinterpret_cast<const double2 *>(out + i);
+    a0 = fma(l0.x, v0.x, a0); a1 = fma(l0.y, v0.y, a1);
+  }
+  double a = (a0 + a1) + (b0 + b1);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  if (lane == 0) far_out[(size_t)split * part_ld + (c - Jp)] = a;
+}
+
+// near[c] = sum_{i < W} L[J + i, Jp + c] out[J + i],  c < Wp: one wave per column
+__global__ __launch_bounds__(256) void gpak_bwd_near_f64(int J, int W, int Jp, const double *__restrict__ L, long ld,
+                                                          const double *__restrict__ out, double *__restrict__ near_out) {
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const double *Lc = L + J + (size_t)(Jp + c) * ld;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = 2 * lane; i < W; i += 128) {
+    const double2 l = *reinterpret_cast<const double2 *>(Lc + i), x = *reinterpret_cast<const double2 *>(out + J + i);
+    a0 = fma(l.x, x.x, a0); a1 = fma(l.y, x.y, a1);
+  }
+  double a = a0 + a1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  if (lane == 0) near_out[c] = a;
+}
+
+// scratch: (2 * BS_SPLITS + 2) * NB doubles (two sets of far partials + near).  OP: per block column (stride op_stride,
+// leading dimension RL) R_b as built by gpak_launch_diag_inverse and, with_T, T_b in the rows below it (`extra` = NB):
+// then one launch per step, else near_{b-1} has a launch of its own
+void gpak_launch_trsv_bwd3(hipStream_t st, int Np, const double *L, long ld, const double *z, double *out, double *scratch,
+                           const double *OP, size_t op_stride, int RL, bool with_T, int NB) {
+  const int nJ = (Np + NB - 1) / NB;
+  double *farb[2] = {scratch, scratch + BS_SPLITS * (size_t)NB},
+         *nearb[2] = {scratch + 2 * BS_SPLITS * (size_t)NB, scratch + (2 * BS_SPLITS + 1) * (size_t)NB};
+  // four 1-KiB pieces in flight per wave and at most 8 row splits of >= 4096 rows: measured against 2 pieces and 4 / 16
+  // splits (profiles/r03_bwd_fused.txt: 1.02-1.05 ms against 1.05-1.08, 1.08-1.11 and 1.11-1.13 at N = 32768)
+  int nsplit_in = 0;
+  for (int b = nJ - 1; b >= 0; b--) {
+    const int J = b * NB, W = min(NB, Np - J);
+    const int Jp = b > 0 ? J - NB : 0, Wp = b > 0 ? NB : 0;
+    const int rows = Np - (J + W);
+    int Rs = 0, per = 128;
+    if (rows > 0 && b > 0) {
+      Rs = min(8, (rows + 4095) / 4096);
+      per = ((rows + Rs - 1) / Rs + 127) / 128 * 128;
+    }
+    const int nmv = (W + (with_T ? Wp : 0)) / BS_ROWS;
+    const double *Rb = OP + (size_t)b * op_stride;
+    hipLaunchKernelGGL(gpak_bwd_step_f64<4>, dim3(nmv + (Wp / 4) * Rs), dim3(256), 0, st, Np, J, W, Jp, Wp, Rb, Rb + W, RL, z,
+                       farb[b & 1], nsplit_in, b < nJ - 1 ? nearb[b & 1] : (const double *)nullptr, NB, out, nearb[(b + 1) & 1],
+                       farb[(b + 1) & 1], per, Rs, nmv, L, ld);
+    if (!with_T && b > 0)
+      hipLaunchKernelGGL(gpak_bwd_near_f64, dim3(Wp / 4), dim3(256), 0, st, J, W, Jp, L, ld, out, nearb[(b + 1) & 1]);
+    nsplit_in = Rs;
   }
 }
 

@@ -17,6 +17,7 @@ DIST_EXPANSION, DIST_DIRECT = 0, 1
 COMPAT_VARCLAMP, COMPAT_SN2SKIP = 1, 2
 OPT_MEMOISE, OPT_NB_OUTER, OPT_PROFILE, OPT_LOOKAHEAD = 1, 2, 3, 4
 OPT_NB_WIDE, OPT_NB_WIDE_ROWS, OPT_TAIL_ROWS, OPT_FIRST_NARROW, OPT_INV512, OPT_POTRF_CO, OPT_PRED_BATCH = 5, 6, 7, 8, 9, 10, 11
+OPT_BWD_FUSED = 12
 KERN_EXPANS, KERN_EXP, KERN_RBF = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)

@@ -115,6 +115,8 @@ int gpak_set_kernel(gpak_ctx *ctx, int nterms, const int *kinds, const double *p
 #define GPAK_OPT_INV512       9  /* 1 (default): explicit 512-block inverses for the back substitution             */
 #define GPAK_OPT_POTRF_CO    10  /* 128 x 128 block kernel: 0 always 8 waves, 2 always the 4-wave build, 1 as needed */
 #define GPAK_OPT_PRED_BATCH  11  /* test points per prediction batch (0: 16384 fp64, 65536 fp32)                    */
+#define GPAK_OPT_BWD_FUSED   12  /* back substitution (needs INV512): 0 three launches per 512 columns, 1 the far column
+                                    dots of the next block under this block's diagonal step, 2 (default) one launch  */
 int gpak_set_option(gpak_ctx *ctx, int option, long value);
 
 /* ---- hot path --------------------------------------------------------------------------- */

@@ -482,7 +482,7 @@ def test_options_and_two_live_contexts(orc):
                          (gpak.OPT_NB_OUTER, 1024), (gpak.OPT_NB_OUTER, 512), (gpak.OPT_LOOKAHEAD, 1),
                          (gpak.OPT_NB_WIDE_ROWS, 1024), (gpak.OPT_FIRST_NARROW, 0), (gpak.OPT_NB_WIDE, 0),
                          (gpak.OPT_TAIL_ROWS, 0), (gpak.OPT_TAIL_ROWS, 1 << 30), (gpak.OPT_POTRF_CO, 0),
-                         (gpak.OPT_POTRF_CO, 2), (gpak.OPT_POTRF_CO, 1), (gpak.OPT_INV512, 0)):
+                         (gpak.OPT_POTRF_CO, 2), (gpak.OPT_POTRF_CO, 1), (gpak.OPT_BWD_FUSED, 0), (gpak.OPT_BWD_FUSED, 1), (gpak.OPT_BWD_FUSED, 2), (gpak.OPT_INV512, 0)):
             a.set_option(opt, val)
             a.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)                    # invalidates like the reference
             v = a.logLikelihood()
@@ -491,7 +491,9 @@ def test_options_and_two_live_contexts(orc):
         a.set_option(gpak.OPT_LOOKAHEAD, 1)
         a.set_option(gpak.OPT_NB_OUTER, 512)
         a.set_option(gpak.OPT_INV512, 1)
-        for opt, val in ((gpak.OPT_NB_OUTER, 100), (gpak.OPT_NB_WIDE, 700), (gpak.OPT_POTRF_CO, 3), (99, 1)):
+        a.set_option(gpak.OPT_BWD_FUSED, 2)
+        for opt, val in ((gpak.OPT_NB_OUTER, 100), (gpak.OPT_NB_WIDE, 700), (gpak.OPT_POTRF_CO, 3), (gpak.OPT_BWD_FUSED, 3),
+                         (99, 1)):
             with pytest.raises(gpak.GpakError):
                 a.set_option(opt, val)                                      # not a multiple of 128 / out of range / unknown
         a.set_option(gpak.OPT_MEMOISE, 1)
