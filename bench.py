@@ -267,7 +267,7 @@ def run_single(args):
                      "achieved": fill_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": fill_gbs / PEAK_HBM_GBS,
                      "algorithmic_bytes": tim["gram_bytes"], "ms": phases["gram_ms"] / args.steps},
             # back substitution (the forward one rides along with the factorisation): L's lower triangle streamed once
-            "solve": {"kernel": "gpak_coldot_split_f64 + gpak_bwd_diag_mv_f64 (back substitution, 64 x 3 launches at N=32768)",
+            "solve": {"kernel": "gpak_bwd_step_f64 (back substitution, one launch per 512 columns: 64 at N=32768)",
                       "bound": "hbm", "algorithmic_bytes": 8.0 * Np * (Np + 512) / 2.0,
                       "achieved": 8.0 * Np * (Np + 512) / 2.0 / (phases["solve_ms"] / args.steps * 1e-3) / 1e9,
                       "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -50,6 +50,7 @@ static GpakTuning read_tuning_env() {
   getb("GPAK_FIRST_NARROW", t.first_narrow);
   geti("GPAK_TAIL_ROWS", t.tail_rows);
   getb("GPAK_SUB_NEXT", t.sub_next);
+  geti("GPAK_NEXT_SPLIT_ROWS", t.next_split_rows);
   getb("GPAK_INV512", t.inv512);
   geti("GPAK_BWD_FUSED", t.bwd_fused);
   geti("GPAK_BWD_BLOCK", t.bwd_block);

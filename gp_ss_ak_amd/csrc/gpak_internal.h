@@ -60,6 +60,8 @@ struct GpakTuning {
   bool first_narrow = true;    // GPAK_FIRST_NARROW  the very first panel is nb_outer wide
   int tail_rows = 12288;       // GPAK_TAIL_ROWS     rows left from which the bulk updates use the CU-masked queue
   bool sub_next = false;       // GPAK_SUB_NEXT      tail: next block column updated sub-panel by sub-panel
+  int next_split_rows = 0;     // GPAK_NEXT_SPLIT_ROWS  rows left from which only the first 128 columns of the next block column are
+                               //                    updated in the panel chain, the others beside the next panel's first step (0: off)
   bool inv512 = true;          // GPAK_INV512        explicit diagonal-block inverses for the back substitution
   int bwd_fused = 2;           // GPAK_BWD_FUSED     back substitution: 0 three launches per step, 1 far column dots under the diagonal
                                //                    step (two launches), 2 one launch (coupling blocks T_b): solve.hip
@@ -328,7 +330,7 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
                           bool co = false, int co_mode = -1);
 int gpak_potrf_blocked(gpak_ctx *ctx);
 void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                       bool zero_inv, bool co = false, int co_mode = -1);
+                       bool zero_inv, bool co = false, int co_mode = -1, hipEvent_t gate = nullptr);
 
 // ---- solve.hip --------------------------------------------------------------------------
 // x := L^-1 x ; x := L^-T x  (x has Np entries) using the inverted diagonal blocks.

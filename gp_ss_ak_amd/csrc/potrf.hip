@@ -494,8 +494,10 @@ void gpak_launch_potrf128(hipStream_t st, double *A, long ld, double *inv, int c
 // M is addressed with GLOBAL (row, column) indices; only columns [J, J+W) are touched, so a
 // rank that stores just this block column passes a virtual base (see dev_api.hip).
 // One level: 128-column steps, each followed by the K=128 update of the columns [j+128, J+W).
+// `gate`: an event the FIRST in-panel update waits for (the update of this panel's columns [J+128, J+W) by the previous
+// panel, when that ran on a side stream: GPAK_NEXT_SPLIT_ROWS)
 static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                             bool zero_inv, bool co, int co_mode) {
+                             bool zero_inv, bool co, int co_mode, hipEvent_t gate = nullptr) {
   for (int j = J; j < J + W; j += PB) {
     double *inv = inv_base + (size_t)(j / PB) * 2 * PB * PB;
     gpak_launch_potrf128(st, M + j + (size_t)j * ld, ld, inv, j, info, zero_inv, co, co_mode);
@@ -504,9 +506,12 @@ static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, 
       double *P = M + (j + PB) + (size_t)j * ld;
       gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, P, ld, inv, PB, 0.0, P, ld, 0, 0, false, false);
       const int nct = (J + W - (j + PB)) / PB;
+      if (gate && j == J) hipStreamWaitEvent(st, gate, 0);
       if (nct > 0)
         gpak_launch_gemm_nt(st, mt, nct, PB, -1.0, P, ld, P, ld, 1.0, M + (j + PB) + (size_t)(j + PB) * ld,
                             ld, 0, 0, true, false);
+    } else if (gate && j == J) {
+      hipStreamWaitEvent(st, gate, 0);
     }
   }
 }
@@ -514,10 +519,10 @@ static void factor_panel_128(hipStream_t st, double *M, long ld, int Np, int J, 
 // of the rest of the panel in between (three-level blocking: 128 / MID / W).
 #define GPAK_PANEL_MID 512
 void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W, double *inv_base, int *info,
-                       bool zero_inv, bool co, int co_mode) {
+                       bool zero_inv, bool co, int co_mode, hipEvent_t gate) {
   for (int j = J; j < J + W; j += GPAK_PANEL_MID) {
     const int w = (J + W - j) < GPAK_PANEL_MID ? (J + W - j) : GPAK_PANEL_MID;
-    factor_panel_128(st, M, ld, Np, j, w, inv_base, info, zero_inv, co, co_mode);
+    factor_panel_128(st, M, ld, Np, j, w, inv_base, info, zero_inv, co, co_mode, j == J ? gate : nullptr);
     const int c0 = j + w, nct = (J + W - c0) / PB, mt = (Np - c0) / PB;
     if (nct > 0 && mt > 0) {
       const double *P = M + c0 + (size_t)j * ld;
@@ -525,9 +530,9 @@ void gpak_factor_panel(hipStream_t st, double *M, long ld, int Np, int J, int W,
     }
   }
 }
-static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W, bool co) {
+static void factor_panel(gpak_ctx *ctx, hipStream_t st, int J, int W, bool co, hipEvent_t gate = nullptr) {
   // ctx->dInv is zeroed once in gpak_set_train and only ever written inside its triangles
-  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false, co, ctx->tune.potrf_co);
+  gpak_factor_panel(st, ctx->dM, ctx->ld, ctx->Np, J, W, ctx->dInv, ctx->dInfo, false, co, ctx->tune.potrf_co, gate);
 }
 
 // Chain-bound tail: the same panel factorisation (W <= 512), but the update of the NEXT block column [J1, J2) is
@@ -634,11 +639,17 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   // measurable; off unless GPAK_SUB_NEXT=1 (kept: the multi-GPU schedule is built the same way and tests compare)
   const bool sub_next = ctx->tune.sub_next;
   bool next_col_done = false;   // the next block column already has this panel's update (applied per sub-panel)
+  // GPAK_NEXT_SPLIT_ROWS: in the chain-bound tail only the first 128 columns of the next block column take this panel's
+  // K = W update on the panel stream; the others get it on the side stream while the next panel's first block kernel
+  // and panel solve run, and that panel's first in-panel update waits for it (`gate`)
+  const int next_split_rows = ctx->stream_x && ctx->lookahead ? ctx->tune.next_split_rows : 0;
+  hipEvent_t gate = nullptr;
   for (int b = 0; b < nJ; b++) {
     const int J = Js[b], W = Js[b + 1] - J;
     const int J1n = J + W, J2n = J1n < Np ? Js[b + 2] : Np;
     const bool tail_step = sub_next && ctx->lookahead && ctx->stream_x && W <= 512 && J1n < Np && Np - J1n <= tail_rows;
     if (tail_step) {
+      if (gate) GPAK_HIP(hipStreamWaitEvent(sp, gate, 0));
       int rc = factor_panel_tail(ctx, sp, ctx->stream_x, J, W, J1n, J2n, b > 0 ? EU[b - 1] : nullptr, EX, EXdone);
       if (rc) return rc;
       next_col_done = true;
@@ -646,7 +657,7 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
       // panel b is factored while the bulk update of panel b-1 (rows >= J + W) runs: on the unmasked stream that
       // update holds two 210-VGPR waves on every SIMD of the chip, and only the 4-wave, 80-VGPR potrf128 fits beside it
       const bool beside_bulk = ctx->lookahead && b > 0 && !(ctx->stream_tail && Np - (J + W) <= tail_rows);
-      factor_panel(ctx, sp, J, W, beside_bulk);
+      factor_panel(ctx, sp, J, W, beside_bulk, gate);
       next_col_done = false;
     }
     GPAK_HIP(hipEventRecord(EF[b], sp));
@@ -676,8 +687,20 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
     if (J1 >= Np) break;
     const int J2 = Js[b + 2];
     // next panel's columns first, on the panel stream (after the previous bulk update)
+    gate = nullptr;
     if (next_col_done) {
       GPAK_HIP(hipStreamWaitEvent(sp, EXdone, 0));
+    } else if (next_split_rows > 0 && Np - J1 <= next_split_rows && J2 - J1 > PB && J2 - J1 <= GPAK_PANEL_MID) {
+      hipStream_t sx = ctx->stream_x;
+      GPAK_HIP(hipStreamWaitEvent(sx, EF[b], 0));
+      if (b > 0) {
+        GPAK_HIP(hipStreamWaitEvent(sx, EU[b - 1], 0));
+        GPAK_HIP(hipStreamWaitEvent(sp, EU[b - 1], 0));
+      }
+      update_cols(ctx, sp, J, W, J1, J1 + PB, false);
+      update_cols(ctx, sx, J, W, J1 + PB, J2, false);
+      GPAK_HIP(hipEventRecord(EXdone, sx));
+      gate = EXdone;
     } else {
       if (b > 0) GPAK_HIP(hipStreamWaitEvent(sp, EU[b - 1], 0));
       update_cols(ctx, sp, J, W, J1, J2, false);
