@@ -53,6 +53,7 @@ static GpakTuning read_tuning_env() {
   geti("GPAK_NEXT_SPLIT_ROWS", t.next_split_rows);
   getb("GPAK_INV512", t.inv512);
   geti("GPAK_BWD_FUSED", t.bwd_fused);
+  geti("GPAK_SBASE_ROWS", t.sbase_rows);
   geti("GPAK_BWD_BLOCK", t.bwd_block);
   getb("GPAK_LOOKAHEAD", t.lookahead);
   getb("GPAK_FWD_IN_FACTOR", t.fwd_in_factor);

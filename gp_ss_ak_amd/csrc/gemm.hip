@@ -45,7 +45,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // TRAILING only names the instantiation (the bulk trailing update gets its own line in rocprofv3 statistics).
 // K0MAP (the distributed gradient's B^-1 = G G^T on row-cyclic slabs of G): the k-loop of tile row ti starts at global
 // row block ti * cyc_tpb + cyc_lt0 (the cyc_* parameters are reused; no cyclic column map in that instantiation).
-template <int RS_D, int RS_OCC, bool TRAILING, bool K0MAP = false>
+template <int RS_D, int RS_OCC, bool TRAILING, bool K0MAP = false, bool SBASE = false>
 __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double alpha, const double *A, long lda,
                                                                const double *B, long ldb, double beta, double *C,
                                                                long ldc, int rb0, int cb0, int lower_skip, int mt,
@@ -99,9 +99,25 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
   // One 16-B load feeds TWO fragments: lane (l15, l4) fetches rows 32h + 2*l15, +1 of k-column 4s + l4 and
   // uses them as its element of tiles 2h and 2h+1, i.e. MFMA tile i covers the rows 32(i>>1) + 2j + (i&1),
   // j = 0..15, of the wave's 64 -- a fixed permutation that the epilogue undoes (16 lanes = 256 B contiguous).
-  const d2 *Ap = reinterpret_cast<const d2 *>(A + (size_t)art * TM + wr * 64 + 2 * l15 + (size_t)(4 * kstep0 + l4) * lda);
-  const d2 *Bp = reinterpret_cast<const d2 *>(B + (size_t)gct * TN + wc * 64 + 2 * l15 + (size_t)(4 * kstep0 + l4) * ldb);
-  const size_t sa = 2 * (size_t)lda, sb = 2 * (size_t)ldb;  // 4 k-columns, in 16-B units
+  // Operand addresses = a wave-uniform 64-bit base in scalar registers, advanced on the SCALAR unit, + a fixed 32-bit
+  // lane offset (the SADDR form of global_load): no vector instruction in the loop but the MFMAs and the loads.  Every
+  // vector ALU instruction beside the MFMAs holds the matrix pipe for 8-16 cycles (tools/mfma_f32_loop.hip: the fp32
+  // loop with the two v_lshl_add_u64 per k-step the compiler makes of per-lane pointers 146 TFLOP/s, with v_add_co
+  // pairs 142, with scalar bases 155.6 of 157).  RS_LAUNDER keeps loop-strength reduction from turning base + offset
+  // back into per-lane 64-bit pointers.
+  // SBASE is chosen by the launcher for the bulk update while the trailing matrix is large (GpakTuning::sbase_rows):
+  // alone the kernel gains 1.2-1.6 % at K >= 512 and LOSES 4-13 % at K = 128 / 256 (more issue-stall cycles per wave
+  // around the short loop, tools/ab_pmc.sh), and in situ the tighter loop starves the panel chain beside it -- with
+  // scalar bases in every bulk update the step was 2 ms SLOWER at N = 32768 and 10 % slower at N = 8192, where the chain
+  // is all there is (profiles/r03_scalar_base.txt).
+  constexpr bool SB = SBASE;
+  const char *Ac = reinterpret_cast<const char *>(A + (size_t)art * TM + wr * 64 + (size_t)(4 * kstep0) * lda);
+  const char *Bc = reinterpret_cast<const char *>(B + (size_t)gct * TN + wc * 64 + (size_t)(4 * kstep0) * ldb);
+  unsigned aoff = (unsigned)((2 * l15 + (size_t)l4 * lda) * sizeof(double));
+  unsigned boff = (unsigned)((2 * l15 + (size_t)l4 * ldb) * sizeof(double));
+  const size_t sa = 4 * (size_t)lda * sizeof(double), sb = 4 * (size_t)ldb * sizeof(double);  // 4 k-columns, in bytes
+  const char *Apl = Ac + aoff, *Bpl = Bc + boff;   // the per-lane pointers of the !SB build
+#define RS_LAUNDER if (SB) asm volatile("" : "+v"(aoff), "+v"(boff));
 
   d4 acc[4][4];
 #pragma unroll
@@ -110,11 +126,11 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
     for (int ni = 0; ni < 4; ni++) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
   d2 ra[RS_D][2], rbv[RS_D][2];
-#define RS_LOAD(slot_)                                                             \
-  _Pragma("unroll") for (int h = 0; h < 2; h++) ra[slot_][h] = Ap[16 * h];        \
-  _Pragma("unroll") for (int h = 0; h < 2; h++) rbv[slot_][h] = Bp[16 * h];       \
-  Ap += sa;                                                                        \
-  Bp += sb;
+#define RS_LD16(p_) (*reinterpret_cast<const d2 *>(p_))
+#define RS_LOAD(slot_)                                                                                          \
+  _Pragma("unroll") for (int h = 0; h < 2; h++) ra[slot_][h] = SB ? RS_LD16(Ac + 256 * h + aoff) : RS_LD16(Apl + 256 * h);  \
+  _Pragma("unroll") for (int h = 0; h < 2; h++) rbv[slot_][h] = SB ? RS_LD16(Bc + 256 * h + boff) : RS_LD16(Bpl + 256 * h); \
+  if (SB) { Ac += sa; Bc += sb; } else { Apl += sa; Bpl += sb; }
 #define RS_MFMA(slot_)                                                             \
   _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                 \
       _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                             \
@@ -127,6 +143,7 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
   for (int s = 0; s < RS_D; s++) { RS_LOAD(s) }
   int g = 0;
   for (; g + 2 * RS_D <= n; g += RS_D) {
+    RS_LAUNDER
 #pragma unroll
     for (int s = 0; s < RS_D; s++) {
       RS_MFMA(s)
@@ -146,6 +163,7 @@ __global__ __launch_bounds__(256, RS_OCC) void gpak_gemm_nt_f64_rs(int K, double
     if (s < r) { RS_MFMA(s) }
 #undef RS_LOAD
 #undef RS_MFMA
+#undef RS_LAUNDER
 
   // in-place product (the panel solve P <- P * inv^T, one tile column): the workgroup's C rows are its
   // own A rows, which the neighbouring wave is still reading -- the only place the waves must meet
@@ -377,7 +395,11 @@ void gpak_launch_gemm_nt(hipStream_t st, int mt, int nt, int K, double alpha, co
                          ldb, beta, C, ldc, row_block0, col_block0, ls, 8 * mt, nt, kr);
     return;
   }
-  if (trailing)
+  const int sbase_rows = gpak_tuning().sbase_rows;
+  if (trailing && sbase_rows > 0 && (long)mt * TM > sbase_rows)
+    hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C,
+                       ldc, row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0, lr);
+  else if (trailing)
     hipLaunchKernelGGL((gpak_gemm_nt_f64_rs<4, 2, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc,
                        row_block0, col_block0, lower_skip ? 1 : 0, mt, nt, k0_by_row ? 1 : 0, 0, 0, 1, 0, lr);
   else

@@ -230,9 +230,15 @@ __global__ __launch_bounds__(256, OCC) void gpak_gemm_nt_f32_rsw(int K, float al
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w & 1, wc = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const f4 *Ap = reinterpret_cast<const f4 *>(A + (size_t)ti * TM + wr * 64 + 4 * l15 + (size_t)l4 * lda);
-  const f4 *Bp = reinterpret_cast<const f4 *>(B + (size_t)tj * TN + wc * 64 + 4 * l15 + (size_t)l4 * ldb);
-  const size_t sa = (size_t)lda, sb = (size_t)ldb;  // 4 k-columns in 16-B units
+  // operand addresses = wave-uniform bases in scalar registers (advanced on the scalar unit) + a fixed 32-bit lane offset:
+  // no vector ALU instruction in the loop but the MFMAs -- each one holds the matrix pipe for 8-16 cycles
+  // (tools/mfma_f32_loop.hip: 146 -> 155.6 TFLOP/s for this loop without the two v_lshl_add_u64 per k-step)
+  const char *Ac = reinterpret_cast<const char *>(A + (size_t)ti * TM + wr * 64);
+  const char *Bc = reinterpret_cast<const char *>(B + (size_t)tj * TN + wc * 64);
+  unsigned aoff = (unsigned)((4 * l15 + (size_t)l4 * lda) * sizeof(float));
+  unsigned boff = (unsigned)((4 * l15 + (size_t)l4 * ldb) * sizeof(float));
+  const size_t sa = 4 * (size_t)lda * sizeof(float), sb = 4 * (size_t)ldb * sizeof(float);  // 4 k-columns, in bytes
+#define RSW_LD(p_, o_) (*reinterpret_cast<const f4 *>((p_) + (o_)))
   f4 acc[4][4];
   double tot[4][4][4];
 #pragma unroll
@@ -245,9 +251,10 @@ __global__ __launch_bounds__(256, OCC) void gpak_gemm_nt_f32_rsw(int K, float al
   const int n = K / 4;   // k-steps: a multiple of 32 (K is a multiple of 128)
 #pragma unroll
   for (int s = 0; s < RS_D; s++) {
-    ra[s] = *Ap; rbv[s] = *Bp; Ap += sa; Bp += sb;
+    ra[s] = RSW_LD(Ac, aoff); rbv[s] = RSW_LD(Bc, boff); Ac += sa; Bc += sb;
   }
   for (int c0 = 0; c0 < n; c0 += 32) {
+    asm volatile("" : "+v"(aoff), "+v"(boff));   // keeps base + offset from becoming per-lane 64-bit induction variables
 #pragma unroll
     for (int s = 0; s < 32; s++) {
       const int slot = s % RS_D;
@@ -264,7 +271,10 @@ __global__ __launch_bounds__(256, OCC) void gpak_gemm_nt_f32_rsw(int K, float al
           for (int ni = 0; ni < 4; ni++)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(rbv[slot][ni], ra[slot][mi], acc[mi][ni], 0, 0, 0);
       }
-      if (c0 + s + RS_D < n) { ra[slot] = *Ap; rbv[slot] = *Bp; Ap += sa; Bp += sb; }
+      // unconditional (a load under a branch falls back to a vector add of base and offset): the bases stop at the last
+      // k-step, so that the RS_D loads past the end re-read it into slots nobody consumes
+      ra[slot] = RSW_LD(Ac, aoff); rbv[slot] = RSW_LD(Bc, boff);
+      { const bool more = c0 + s + RS_D + 1 < n; Ac += more ? sa : 0; Bc += more ? sb : 0; }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -311,6 +321,12 @@ void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha,
     const int v = tn.f32_rsd;
     if (v == 8)        // one workgroup per CU slot pair: all 512 registers of a SIMD lane for one wave
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<8, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+    else if (v == 12)
+      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<12, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+    else if (v == 16)
+      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<16, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
+    else if (v == 24)
+      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<24, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
     else if (v == 2)
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<2, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
     else

@@ -76,6 +76,8 @@ struct GpakTuning {
   bool bulk_queue = true;      // GPAK_BULK_QUEUE    bulk updates on a queue made by hipExtStreamCreateWithCUMask
   long ld_pad = -1;            // GPAK_LD_PAD        leading-dimension skew in doubles (-1: 32 from Np = 1024 on)
   // kernel selection
+  int sbase_rows = 0;          // GPAK_SBASE_ROWS      bulk updates of more rows than this use the scalar-base build of the kernel (0: never;
+                               //                      measured slower in situ at every threshold: profiles/r03_scalar_base.txt)
   int gemm_small = 160;        // GPAK_GEMM_SMALL      tile grids up to this size take the latency kernel
   int gemm_small_rows = 16;    // GPAK_GEMM_SMALL_ROWS rows per workgroup of that kernel: 16 / 32 / 64
   int super_lr = 3;            // GPAK_SUPER_LR      bulk update: super-tiles of 2^lr x 2^(6-lr) tiles per XCD (3 = 8 x 8)

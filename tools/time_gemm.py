@@ -37,3 +37,21 @@ for Np in SIZES:
         print(f"Np={Np} K={K}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)
         del P
     del C
+# narrow updates (the next block column of the panel chain: Wc = 512 columns, all rows below): latency of one partial wave of
+# workgroups rather than throughput.  GEMM_NARROW=1
+if os.environ.get("GEMM_NARROW"):
+    for Np in (4096, 8192, 16384, 32768):
+        ld = Np + 32
+        Cn = torch.zeros(512 * ld, dtype=torch.float64, device="cuda")
+        for K in (128, 512):
+            P = torch.randn(Np * K, dtype=torch.float64, device="cuda") * 1e-3
+            eng.update_block(P, Np, 0, K, Cn, ld, Np, 0, 512)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                eng.update_block(P, Np, 0, K, Cn, ld, Np, 0, 512)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"narrow Np={Np} Wc=512 K={K}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us", flush=True)
