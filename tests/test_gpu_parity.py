@@ -586,3 +586,32 @@ def test_full_size_properties(gp, N):
     assert rel(mean, (y - SN2 * alpha)[idx]) <= 1e-7
     assert np.all(var - SN2 >= 0) and np.all(var - SN2 < E[6] ** 2 + BIAS)
     gp.set_train(X[:64], y[:64])   # release the 8.6 GB buffer for the following tests
+
+
+@pytest.mark.parametrize("n,sn2", [(3000, 0.016), (3000, 1e-4), (2500, 1e-6)])
+def test_back_substitution_modes_by_residual(orc, n, sn2):
+    """The three back substitutions (GPAK_OPT_BWD_FUSED 0 / 1 / 2: column dots + diagonal product + sum; far dots under
+    the diagonal step; one launch per step with the coupling blocks T_b = L[b,b-1]^T R_b) on well- and ill-conditioned
+    systems (cond(B) ~ 1/sn2): each mode's residual |(K + sn2 I) alpha - y| stays within a small factor of what SciPy's
+    LAPACK solve leaves on the same matrix -- explicit inverses and their products must not cost accuracy."""
+    import scipy.linalg as sla
+    X, y = synth.drillholes(n)
+    K = orc.gram(X, X, E, BIAS, gpak.DIST_DIRECT)
+    A = K + sn2 * np.eye(n)
+    a_ref = sla.cho_solve(sla.cho_factor(A, lower=True), y)
+    r_ref = np.abs(A @ a_ref - y).max()
+    g = gpak.Gpak(0)
+    try:
+        g.set_train(X, y)
+        out = []
+        for mode in (0, 1, 2):
+            g.set_option(gpak.OPT_BWD_FUSED, mode)
+            g.set_params(E, BIAS, sn2, gpak.DIST_DIRECT)
+            a = g.solve_alpha()
+            r = np.abs(A @ a - y).max()
+            out.append((mode, r, np.abs(a - a_ref).max() / np.abs(a_ref).max()))
+    finally:
+        g.close()
+    print(f"\nn={n} sn2={sn2:g}: LAPACK residual {r_ref:.2e}; " + "; ".join(f"mode {m}: residual {r:.2e}, alpha vs LAPACK {d:.1e}" for m, r, d in out))
+    for m, r, d in out:
+        assert r <= 20 * r_ref + 1e-13 * np.abs(y).max(), (m, r, r_ref)
