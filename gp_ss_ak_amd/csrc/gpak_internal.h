@@ -87,7 +87,7 @@ struct GpakTuning {
   bool f32_wide = true;        // GPAK_F32_ACC=plain switches the fp64 accumulation of the fp32 products off
   int f32_rsd = 4;             // GPAK_F32_RSD       operand prefetch depth of the wide-accumulation kernel: 2 / 4 / 8
   int f32_tile = 128;          // GPAK_F32_TILE      wave tile rows of the plain fp32 kernel: 128 / 64
-  int fs_levels[8] = {128, 512, 2048, 8192, 0, 0, 0, 0};   // GPAK_FS_LEVELS_F32  ladder of the fp32 substitution
+  int fs_levels[8] = {128, 512, 2048, 8192, 0, 0, 0, 0};   // GPAK_FS_LEVELS_F32  ladder of the substitution with many right-hand sides (fp32 and fp64 prediction)
   int pred_batch = 0;          // GPAK_PRED_BATCH    test points per batch (0: 16384 fp64, 65536 fp32)
   int pred_ld_skew = 1;        // GPAK_PRED_LD_SKEW  leading dimensions of the test-major batch and of the fp32 factor image
                                //                    are skewed by this many 256-byte units (0: powers of two, as in round 2)

@@ -82,32 +82,37 @@ static int ensure_predict_bufs(gpak_ctx *ctx, int cap, bool want_var) {
 }
 
 // blocked forward substitution on the test-major batch: Wt (mbp x Np, ld ldw) := Wt * L^-T.
-// Two levels like the Cholesky: inside an outer block of 512 columns the 128-column steps
-// (product with the inverted diagonal block, K = 128 update of the rest of the outer block),
-// then ONE K = 512 update of everything to the right -- 4x less C traffic and 4x more MFMA work
-// per tile than updating the whole remainder after every 128 columns.
-#define FS_NB 512
-static void forward_subst_batch(gpak_ctx *ctx, double *Wt, long ldw, int mbp) {
-  const int Np = ctx->Np;
-  const long ld = ctx->ld;
+// A ladder of block widths like the fp32 path below (GpakTuning::fs_levels, 128 / 512 / 2048 / 8192): a block of width
+// lv[k] is solved by its children of width lv[k-1], each followed by ONE K = lv[k-1] update of the rest of the block.
+// Round 3: the two-level form (128-column steps inside 512 columns, then a K = 512 update of everything to the
+// right) left 75 % of the flops in K = 512 products (70.7 TFLOP/s alone); with the ladder they sit in K = 8192 / 2048
+// products (75.7): 72.0 -> 73.1 TFLOP/s for the whole fp64 variance pass in a same-box A/B (the pass is within 5 % of
+// the package power limit either way); same sums to 13 digits.
+static void fs_block_f64(gpak_ctx *ctx, double *Wt, long ldw, int mt, int J0, int W, const std::vector<int> &lv, int k) {
   hipStream_t st = ctx->stream;
-  const int mt = mbp / PB;
-  for (int J = 0; J < Np; J += FS_NB) {
-    const int W = std::min(FS_NB, Np - J);
-    for (int j0 = J; j0 < J + W; j0 += PB) {
-      const double *inv = ctx->dInv + (size_t)(j0 / PB) * 2 * PB * PB;
-      double *Wj = Wt + (size_t)j0 * ldw;
-      gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Wj, ldw, inv, PB, 0.0, Wj, ldw, 0, 0, false, false);
-      const int nin = (J + W - j0 - PB) / PB;
-      if (nin > 0)
-        gpak_launch_gemm_nt(st, mt, nin, PB, -1.0, Wj, ldw, ctx->dM + (j0 + PB) + (size_t)j0 * ld, ld, 1.0,
-                            Wt + (size_t)(j0 + PB) * ldw, ldw, 0, 0, false, false);
-    }
-    const int nrest = (Np - J - W) / PB;
-    if (nrest > 0)
-      gpak_launch_gemm_nt(st, mt, nrest, W, -1.0, Wt + (size_t)J * ldw, ldw, ctx->dM + (J + W) + (size_t)J * ld, ld,
-                          1.0, Wt + (size_t)(J + W) * ldw, ldw, 0, 0, false, false);
+  const long ld = ctx->ld;
+  if (k == 0) {   // W == 128: product with the explicit inverse of the diagonal block
+    const double *inv = ctx->dInv + (size_t)(J0 / PB) * 2 * PB * PB;
+    double *Wj = Wt + (size_t)J0 * ldw;
+    gpak_launch_gemm_nt(st, mt, 1, PB, 1.0, Wj, ldw, inv, PB, 0.0, Wj, ldw, 0, 0, false, false);
+    return;
   }
+  const int cw = lv[k - 1];
+  for (int j0 = J0; j0 < J0 + W; j0 += cw) {
+    const int w = std::min(cw, J0 + W - j0);
+    fs_block_f64(ctx, Wt, ldw, mt, j0, w, lv, k - 1);
+    const int nrest = (J0 + W - j0 - w) / PB;
+    if (nrest > 0)
+      gpak_launch_gemm_nt(st, mt, nrest, w, -1.0, Wt + (size_t)j0 * ldw, ldw, ctx->dM + (j0 + w) + (size_t)j0 * ld, ld, 1.0,
+                          Wt + (size_t)(j0 + w) * ldw, ldw, 0, 0, false, false);
+  }
+}
+static void forward_subst_batch(gpak_ctx *ctx, double *Wt, long ldw, int mbp) {
+  std::vector<int> lv;
+  for (int v : ctx->tune.fs_levels) if (v > 0) lv.push_back(v);
+  if (lv.empty()) lv = {PB, 512};
+  lv.push_back(ctx->Np > lv.back() ? ctx->Np : lv.back() + 1);   // the whole matrix is the top block
+  fs_block_f64(ctx, Wt, ldw, mbp / PB, 0, ctx->Np, lv, (int)lv.size() - 1);
 }
 
 // fp32 images of the factor for a GPAK_F32 context (rebuilt when the factor changes)
