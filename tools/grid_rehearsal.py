@@ -11,9 +11,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gp_ss_ak_amd import gpak, synth  # noqa: E402
-from test_dist_cpp import free_port  # noqa: E402
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 512
