@@ -615,3 +615,25 @@ def test_back_substitution_modes_by_residual(orc, n, sn2):
     print(f"\nn={n} sn2={sn2:g}: LAPACK residual {r_ref:.2e}; " + "; ".join(f"mode {m}: residual {r:.2e}, alpha vs LAPACK {d:.1e}" for m, r, d in out))
     for m, r, d in out:
         assert r <= 20 * r_ref + 1e-13 * np.abs(y).max(), (m, r, r_ref)
+
+
+def test_factor_against_the_vendor_cholesky():
+    """An oracle-independent check on the device itself: torch.linalg.cholesky (hipSOLVER / rocSOLVER dpotrf) of the same
+    B = I + K / sn2 gives the same factor and the same log-determinant (tools/vendor_potrf.py times the two)."""
+    import torch
+    n = 3000
+    X, y = synth.drillholes(n)
+    g = gpak.Gpak(0)
+    try:
+        g.set_train(X, y)
+        g.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        K = g.gram()
+        g.logLikelihood()
+        R = g.chol_upper()                 # the reference keeps the upper factor: B = R^T R
+        ld = g.nlz_terms()[2]
+    finally:
+        g.close()
+    B = torch.from_numpy(np.ascontiguousarray(K)).cuda() / SN2 + torch.eye(n, dtype=torch.float64, device="cuda")
+    L = torch.linalg.cholesky(B).cpu().numpy()
+    assert np.abs(np.triu(R) - L.T).max() <= 1e-11 * np.abs(L).max()
+    assert abs(ld - np.log(np.diag(L)).sum()) <= 1e-12 * abs(ld)
