@@ -202,6 +202,24 @@ def config3(iters, N=32768):
                     "B^-1 (2N^3/3) + the fused pair pass"}
 
 
+def vendor_potrf(sizes, limit_s=420):
+    """The vendor stack's Cholesky of the SAME matrices on the same device: torch.linalg.cholesky, fp64 (ROCm: hipSOLVER /
+    rocSOLVER dpotrf), in a process of its own (tools/vendor_potrf.py --json: torch brings its own HIP runtime, which stays
+    out of the measured process).  A reference point, like cpu_baseline: not the thing measured, not part of the product."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "vendor_potrf.py"), "--json",
+           *[str(n) for n in sizes]]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s)
+        rows = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        if not rows:
+            return {"error": (r.stderr.decode() or "no output")[-300:]}
+        return {"what": "torch.linalg.cholesky, fp64 (hipSOLVER / rocSOLVER dpotrf) of the same B = I + K/sn2 on the same device, "
+                        "own process; library_factor_ms measured in that process too", "sizes": rows}
+    except Exception as ex:   # never let a reference point take the bench line down
+        return {"error": repr(ex)[:300]}
+
+
 def run_single(args):
     from gp_ss_ak_amd import gpak, synth
     N = args.n
@@ -373,6 +391,8 @@ def run_single(args):
                                              "variance_max_rel_diff": float(np.abs(v32[:Mref] - v64).max() / v64.max()),
                                              "mean_max_rel_diff": float(np.abs(m32[:Mref] - m64).max() / np.abs(m64).max())}}
     g.close()
+    if args.vendor and N == 32768:
+        out["vendor_potrf"] = vendor_potrf([N] + ([args.config2] if args.config2 else []))
     if args.config3 and N == 32768:
         out["config3"] = config3(args.config3, N)
     if not args.no_cpu:
@@ -531,6 +551,8 @@ def main():
     ap.add_argument("--grad", type=int, default=0, help="also time this many GradLL evaluations (config 3)")
     ap.add_argument("--calibrate", action="store_true", default=True)
     ap.add_argument("--no-n65536", action="store_true", help="skip the N=65536 sub-run (north_star's scaling size)")
+    ap.add_argument("--vendor", type=int, default=1, help="1: time torch.linalg.cholesky (hipSOLVER / rocSOLVER) on the same matrix as a "
+                    "reference point (N=32768 and the config-2 size)")
     ap.add_argument("--config2", type=int, default=8192, help="size of the configs[1] sub-run (GPU step and the CPU "
                                                                "reference sequence at full size; 0 = skip)")
     ap.add_argument("--config3", type=int, default=3, help="L-BFGS iterations of the configs[2] sub-run through the CLI "

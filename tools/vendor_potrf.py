@@ -1,6 +1,7 @@
 """Reference point from the vendor stack on the same box: torch.linalg.cholesky (fp64, ROCm: hipSOLVER / rocSOLVER dpotrf)
 on the SAME matrix B = I + K / sn2 that the library factors, against the library's factorisation time.
-Usage: python tools/vendor_potrf.py [N ...]   (through gpurun)"""
+Usage: python tools/vendor_potrf.py [--json] [N ...]   (through gpurun; --json: one JSON line per size, what bench.py reads)"""
+import json
 import os
 import sys
 import time
@@ -12,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gp_ss_ak_amd import gpak, synth  # noqa: E402
 
 E = np.array(synth.DEFAULT_EXPANS)
-for N in [int(a) for a in sys.argv[1:]] or [2048, 8192, 16384, 32768]:
+JSON = "--json" in sys.argv
+for N in [int(a) for a in sys.argv[1:] if a != "--json"] or [2048, 8192, 16384, 32768]:
     X, y = synth.drillholes(N)
     g = gpak.Gpak(0)
     g.set_train(X, y)
@@ -39,6 +41,13 @@ for N in [int(a) for a in sys.argv[1:]] or [2048, 8192, 16384, 32768]:
         ts.append((time.perf_counter() - t0) * 1e3)
     ld_t = float(torch.log(torch.diagonal(L)).sum())
     fl = N ** 3 / 3.0
+    if JSON:
+        print(json.dumps({"N": N, "vendor_ms": min(ts[1:]), "vendor_tflops": fl / min(ts[1:]) / 1e9, "library_factor_ms": min(fac[2:]),
+                          "library_tflops": fl / min(fac[2:]) / 1e9, "library_speedup": min(ts[1:]) / min(fac[2:]),
+                          "sum_log_diag": {"vendor": ld_t, "library": ld_lib}}), flush=True)
+        del B, L
+        torch.cuda.empty_cache()
+        continue
     print(f"N={N}: library factorisation {min(fac[2:]):8.3f} ms = {fl / min(fac[2:]) / 1e9:6.1f} TFLOP/s | torch.linalg.cholesky "
           f"{min(ts[1:]):8.3f} ms = {fl / min(ts[1:]) / 1e9:6.1f} TFLOP/s | ratio {min(ts[1:]) / min(fac[2:]):.2f} | "
           f"sum log diag: library {ld_lib:.9f} torch {ld_t:.9f}", flush=True)
