@@ -619,21 +619,17 @@ def test_back_substitution_modes_by_residual(orc, n, sn2):
 
 def test_factor_against_the_vendor_cholesky():
     """An oracle-independent check on the device itself: torch.linalg.cholesky (hipSOLVER / rocSOLVER dpotrf) of the same
-    B = I + K / sn2 gives the same factor and the same log-determinant (tools/vendor_potrf.py times the two)."""
-    import torch
-    n = 3000
-    X, y = synth.drillholes(n)
-    g = gpak.Gpak(0)
-    try:
-        g.set_train(X, y)
-        g.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
-        K = g.gram()
-        g.logLikelihood()
-        R = g.chol_upper()                 # the reference keeps the upper factor: B = R^T R
-        ld = g.nlz_terms()[2]
-    finally:
-        g.close()
-    B = torch.from_numpy(np.ascontiguousarray(K)).cuda() / SN2 + torch.eye(n, dtype=torch.float64, device="cuda")
-    L = torch.linalg.cholesky(B).cpu().numpy()
-    assert np.abs(np.triu(R) - L.T).max() <= 1e-11 * np.abs(L).max()
-    assert abs(ld - np.log(np.diag(L)).sum()) <= 1e-12 * abs(ld)
+    B = I + K / sn2 gives the same factor and the same log-determinant (tools/vendor_potrf.py times the two).  In a
+    process of its own: torch brings its own HIP runtime, which must come up BEFORE the library's and never share a
+    process that initialised the library first (a double free at interpreter exit otherwise)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vendor_worker.py")
+    r = subprocess.run([sys.executable, worker, "3000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:]
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert res["factor_max_abs_diff"] <= 1e-11 * res["factor_max_abs"]
+    assert abs(res["logdet_library"] - res["logdet_vendor"]) <= 1e-12 * abs(res["logdet_vendor"])
