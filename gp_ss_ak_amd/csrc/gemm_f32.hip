@@ -321,12 +321,8 @@ void gpak_launch_gemm_nt_f32(hipStream_t st, int mt, int nt, int K, float alpha,
     const int v = tn.f32_rsd;
     if (v == 8)        // one workgroup per CU slot pair: all 512 registers of a SIMD lane for one wave
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<8, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
-    else if (v == 12)
-      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<12, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
-    else if (v == 16)
+    else if (v == 16)  // the deepest ring one wave per SIMD has registers for (profiles/r03_f32_prediction.txt: 8 / 16 -> 128 / 131.5)
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<16, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
-    else if (v == 24)
-      hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<24, 1>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
     else if (v == 2)
       hipLaunchKernelGGL((gpak_gemm_nt_f32_rsw<2, 2>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, mt, nt);
     else
