@@ -47,6 +47,8 @@ static GpakTuning read_tuning_env() {
   geti("GPAK_NB_OUTER", t.nb_outer);
   geti("GPAK_NB_WIDE", t.nb_wide); t.nb_wide = t.nb_wide / GPAK_TILE * GPAK_TILE;
   geti("GPAK_NB_WIDE_ROWS", t.nb_wide_rows);
+  geti("GPAK_NB_XWIDE", t.nb_xwide); t.nb_xwide = t.nb_xwide / GPAK_TILE * GPAK_TILE;
+  geti("GPAK_NB_XWIDE_ROWS", t.nb_xwide_rows);
   getb("GPAK_FIRST_NARROW", t.first_narrow);
   geti("GPAK_TAIL_ROWS", t.tail_rows);
   getb("GPAK_SUB_NEXT", t.sub_next);

@@ -57,6 +57,8 @@ struct GpakTuning {
   int nb_outer = 512;          // GPAK_NB_OUTER      outer panel width
   int nb_wide = 1024;          // GPAK_NB_WIDE       panel width while more than nb_wide_rows rows are left (0: off)
   int nb_wide_rows = 16384;    // GPAK_NB_WIDE_ROWS
+  int nb_xwide = 2048;         // GPAK_NB_XWIDE      ... and while more than nb_xwide_rows rows are left (0: off)
+  int nb_xwide_rows = 32768;   // GPAK_NB_XWIDE_ROWS
   bool first_narrow = true;    // GPAK_FIRST_NARROW  the very first panel is nb_outer wide
   int tail_rows = 12288;       // GPAK_TAIL_ROWS     rows left from which the bulk updates use the CU-masked queue
   bool sub_next = false;       // GPAK_SUB_NEXT      tail: next block column updated sub-panel by sub-panel

@@ -603,13 +603,19 @@ int gpak_potrf_blocked(gpak_ctx *ctx) {
   // "rows left" threshold; only applies when nb_outer is narrower than the wide width.
   const int nb_wide = ctx->tune.nb_wide / PB * PB;   // 0: off
   const int nb_wide_rows = ctx->tune.nb_wide_rows;
+  // a third tier for trailing matrices beyond N = 32768: 2048-column panels while more than 32768 rows are left
+  // (N=65536: 1295.0 -> 1285.5 ms with 2048 / 32768 alone, tools/time_sizes.py; nothing changes at N <= 32768)
+  const int nb_xwide = ctx->tune.nb_xwide / PB * PB, nb_xwide_rows = ctx->tune.nb_xwide_rows;
   std::vector<int> Js;
   // the very first panel has nothing to hide behind: keep it narrow so that the first bulk update starts early
   // (measured at N=32768, 30-step A/B inside one box: 182.46 -> 181.90 ms)
   const bool first_narrow = ctx->tune.first_narrow;
   for (int J = 0; J < Np;) {
     Js.push_back(J);
-    J += (nb_wide > NB && Np - J > nb_wide_rows && !(first_narrow && J == 0)) ? nb_wide : NB;
+    const bool first = first_narrow && J == 0;
+    J += (nb_xwide > NB && nb_xwide > nb_wide && Np - J > nb_xwide_rows && !first) ? nb_xwide
+         : (nb_wide > NB && Np - J > nb_wide_rows && !first)                        ? nb_wide
+                                                                                    : NB;
   }
   const int nJ = (int)Js.size();
   Js.push_back(Np);
