@@ -5,6 +5,7 @@ against the Armadillo CPU path.  The tests hold the HIP path to far tighter boun
 the oracle; each bound is written next to its assert.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -633,3 +634,105 @@ def test_factor_against_the_vendor_cholesky():
     res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert res["factor_max_abs_diff"] <= 1e-11 * res["factor_max_abs"]
     assert abs(res["logdet_library"] - res["logdet_vendor"]) <= 1e-12 * abs(res["logdet_vendor"])
+
+
+def test_tuning_environment_matrix():
+    """Every schedule / kernel-selection knob that is only reachable through the GPAK_* environment (read once per process,
+    re-read by gpak_reload_tuning) in combinations that push the code through its less-travelled branches at small sizes:
+    three panel tiers inside a 5000-row matrix, wide back-substitution blocks with the fused step, the scalar-base build
+    forced on, split and sub-panel updates of the next block column, a partial last block, other ladders.  nlZ, alpha,
+    the gradient and a prediction equal the default build's to rounding."""
+    from gp_ss_ak_amd import _lib
+    lib = _lib.load()
+    Xte = synth.test_points(300)
+    cases = [
+        {},
+        {"GPAK_NB_XWIDE": "1024", "GPAK_NB_XWIDE_ROWS": "3000", "GPAK_NB_WIDE": "768", "GPAK_NB_WIDE_ROWS": "1500", "GPAK_NB_OUTER": "256"},
+        {"GPAK_NB_XWIDE": "0", "GPAK_NB_WIDE": "0", "GPAK_TAIL_ROWS": "100000"},
+        {"GPAK_BWD_BLOCK": "1024", "GPAK_BWD_FUSED": "2"}, {"GPAK_BWD_BLOCK": "2048", "GPAK_BWD_FUSED": "1"},
+        {"GPAK_BWD_BLOCK": "1024", "GPAK_BWD_FUSED": "0"}, {"GPAK_INV512": "0"},
+        {"GPAK_SBASE_ROWS": "1"}, {"GPAK_NEXT_SPLIT_ROWS": "100000"}, {"GPAK_SUB_NEXT": "1", "GPAK_TAIL_ROWS": "100000"},
+        {"GPAK_NEXT_SPLIT_ROWS": "100000", "GPAK_SUB_NEXT": "1", "GPAK_NB_OUTER": "384"},
+        {"GPAK_FS_LEVELS_F32": "128,512"}, {"GPAK_FS_LEVELS_F32": "128,256,1024"}, {"GPAK_GEMM_SMALL": "0"},
+        {"GPAK_GEMM_SMALL": "100000", "GPAK_GEMM_SMALL_ROWS": "64"}, {"GPAK_POTRF_CO": "2", "GPAK_LOOKAHEAD": "0"},
+        {"GPAK_FWD_IN_FACTOR": "0"}, {"GPAK_TAIL_MASK": "0", "GPAK_BULK_QUEUE": "0"}, {"GPAK_LD_PAD": "0"},
+        {"GPAK_SUPER_LR": "2"}, {"GPAK_SUPER_LR": "4", "GPAK_SBASE_ROWS": "1"}, {"GPAK_FILL_FAST": "0", "GPAK_KMV_SYM": "0"},
+    ]
+    keys = sorted({k for c in cases for k in c})
+    saved = {k: os.environ.get(k) for k in keys}
+    ref = {}
+    try:
+        for n in (5000, 1300):
+            X, y = synth.drillholes(n)
+            for c in cases:
+                for k in keys:
+                    os.environ.pop(k, None)
+                os.environ.update(c)
+                lib.gpak_reload_tuning()
+                g = gpak.Gpak(0)
+                try:
+                    g.set_train(X, y)
+                    g.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+                    got = (g.logLikelihood(), g.solve_alpha(), g.GradLL(), g.posteriorMeanVar(Xte))
+                finally:
+                    g.close()
+                if not c:
+                    ref[n] = got
+                    continue
+                r = ref[n]
+                assert abs(got[0] - r[0]) <= 1e-11 * abs(r[0]), (n, c)
+                assert rel(got[1], r[1]) <= 1e-9, (n, c)
+                assert rel(got[2], r[2]) <= 1e-8, (n, c)
+                assert rel(got[3][0], r[3][0]) <= 1e-9 and rel(got[3][1], r[3][1]) <= 1e-9, (n, c)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib.gpak_reload_tuning()
+
+
+def test_fp32_kernel_builds_and_ladders():
+    """Every build of the fp32 wide-accumulation product the launcher can pick (GPAK_F32_RSD 2 / 4 at two waves per SIMD,
+    8 / 16 at one), the plain kernels (GPAK_F32_ACC=plain, both tiles) and other ladders: the GPAK_F32 variance against the
+    fp64 context's on the same points, at a size where the long products (K up to 4096) run."""
+    from gp_ss_ak_amd import _lib
+    lib = _lib.load()
+    n, M = 5000, 700
+    X, y = synth.drillholes(n)
+    Xte = synth.test_points(M)
+    g = gpak.Gpak(0)
+    try:
+        g.set_train(X, y)
+        g.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+        m64, v64 = g.posteriorMeanVar(Xte)
+    finally:
+        g.close()
+    cases = [{}, {"GPAK_F32_RSD": "2"}, {"GPAK_F32_RSD": "8"}, {"GPAK_F32_RSD": "16"}, {"GPAK_F32_ACC": "plain"},
+             {"GPAK_F32_ACC": "plain", "GPAK_F32_TILE": "64"}, {"GPAK_FS_LEVELS_F32": "128,512"},
+             {"GPAK_FS_LEVELS_F32": "128,256,1024,2048"}, {"GPAK_PRED_BATCH": "512"}, {"GPAK_PRED_LD_SKEW": "0"}]
+    keys = sorted({k for c in cases for k in c})
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        for c in cases:
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(c)
+            lib.gpak_reload_tuning()
+            g32 = gpak.Gpak(0, gpak.F32)
+            try:
+                g32.set_train(X, y)
+                g32.set_params(E, BIAS, SN2, gpak.DIST_DIRECT)
+                m32, v32 = g32.posteriorMeanVar(Xte)
+            finally:
+                g32.close()
+            assert rel(m32, m64) <= 1e-9, c
+            assert np.abs(v32 - v64).max() <= (2e-4 if c.get("GPAK_F32_ACC") == "plain" else 2e-5) * v64.max(), (c, np.abs(v32 - v64).max() / v64.max())
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib.gpak_reload_tuning()
