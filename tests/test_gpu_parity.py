@@ -736,3 +736,50 @@ def test_fp32_kernel_builds_and_ladders():
             else:
                 os.environ[k] = v
         lib.gpak_reload_tuning()
+
+
+def test_seeded_random_cases_against_lapack(orc):
+    """Twenty-four seeded random problems -- sizes from 1 to 3000 (most not multiples of 128 or 512), noise variances from
+    1e-5 to 1, length scales, angles, signal variance and bias drawn over two decades, both distance forms -- against
+    SciPy's LAPACK on the oracle's Gram: R^T R = B, the residual of alpha at LAPACK's level, nlZ, mean and variance."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(20260305)
+    g = gpak.Gpak(0)
+    try:
+        for case in range(24):
+            n = int(rng.choice([1, 2, 7, 127, 128, 129, 300, 511, 513, 1000, 1537, 2049, 3000]))
+            sn2 = float(10 ** rng.uniform(-5, 0))
+            e = np.array([rng.uniform(0, np.pi), 10 ** rng.uniform(-1, 1), rng.uniform(0, np.pi), 10 ** rng.uniform(-1, 1),
+                          rng.uniform(0, np.pi), 10 ** rng.uniform(-1, 1), 10 ** rng.uniform(-1, 0.5), 0.6])
+            bias = float(10 ** rng.uniform(-3, 0))
+            mode = gpak.DIST_DIRECT if case % 3 else gpak.DIST_EXPANSION
+            X, y = synth.drillholes(max(n, 8))
+            X, y = np.asfortranarray(X[:n]), y[:n].copy()
+            Xte = synth.test_points(40)
+            g.set_train(X, y)
+            g.set_params(e, bias, sn2, mode)
+            nlz = g.logLikelihood()
+            q, slp, ld = g.nlz_terms()
+            alpha = g.solve_alpha()
+            R = g.chol_upper()
+            mean, var = g.posteriorMeanVar(Xte)
+            Ko = orc.gram(X, X, e, bias, mode)
+            tag = (case, n, sn2, mode)
+            K = g.gram()                  # the linear algebra below is held against the matrix the device itself built ...
+            g.set_params(e, bias, sn2, mode)
+            assert rel(K, Ko) <= (1e-12 if mode == gpak.DIST_DIRECT else 2e-7), tag   # ... and that against the oracle's
+            A = K + sn2 * np.eye(n)
+            B = np.eye(n) + K / sn2
+            cf = sla.cho_factor(A, lower=True)
+            a_ref = sla.cho_solve(cf, y)
+            assert rel(R.T @ R, B) <= 1e-12, tag
+            assert np.abs(A @ alpha - y).max() <= 50 * np.abs(A @ a_ref - y).max() + 1e-12 * np.abs(y).max(), tag
+            ld_ref = np.log(np.diag(sla.cholesky(B, lower=True))).sum()
+            assert abs(ld - ld_ref) <= 1e-10 * max(1.0, abs(ld_ref)), tag
+            Ks = orc.gram(X, Xte, e, bias, mode)
+            m_ref = Ks.T @ a_ref
+            # the mean inherits cond(A) ~ 1/sn2 times the rounding of alpha (and, in expansion form, of K): north_star's 1e-5
+            assert rel(mean, m_ref) <= 1e-5, tag
+            assert np.isfinite(nlz) and np.isfinite(var).all() and (var > -1e-8 * (e[6] ** 2 + bias)).all(), tag
+    finally:
+        g.close()
